@@ -1,0 +1,76 @@
+"""Batch assembly for the sampling boundary (reference ``src/datasets.py:332-375, 476-512``).
+
+Only the two functions ``DDPM.sample_chain`` needs: ``collate`` (padding, int8 atom/edge masks)
+and ``create_templates_for_linker_generation``.  The dataset classes / SDF preprocessing of the
+reference are RDKit-bound I/O and out of scope.
+
+The int8 quirk is part of the contract: ``edge_mask`` is built in int8 and multiplied by
+``~eye`` (bitwise NOT on int8: 0 -> -1, 1 -> -2), so real i!=j pairs carry -1, real self
+pairs -2 and any pair with a padded endpoint 0 (datasets.py:366-369, const.py:7).
+"""
+import torch
+
+from . import const
+
+
+def collate(batch):
+    """Pad a list of per-molecule dicts into ``[B,N,...]`` tensors (datasets.py:332-375)."""
+    out = {}
+    for data in batch:
+        for key, value in data.items():
+            out.setdefault(key, []).append(value)
+
+    for key, value in out.items():
+        if key in const.DATA_LIST_ATTRS:
+            continue
+        if key in const.DATA_ATTRS_TO_PAD:
+            out[key] = torch.nn.utils.rnn.pad_sequence(value, batch_first=True, padding_value=0)
+            continue
+        raise Exception(f'Unknown batch key: {key}')
+
+    atom_mask = (out['fragment_mask'].bool() | out['linker_mask'].bool()).to(const.TORCH_INT)
+    out['atom_mask'] = atom_mask[:, :, None]
+    batch_size, n_nodes = atom_mask.size()
+
+    if 'pocket_mask' in batch[0].keys():
+        # MOAD / pockets: "edge_mask" is the per-node batch index (datasets.py:359-364)
+        out['edge_mask'] = torch.arange(batch_size, dtype=const.TORCH_INT, device=atom_mask.device) \
+            .repeat_interleave(n_nodes)
+    else:
+        edge_mask = atom_mask[:, None, :] * atom_mask[:, :, None]
+        diag_mask = ~torch.eye(n_nodes, dtype=const.TORCH_INT, device=atom_mask.device).unsqueeze(0)
+        edge_mask = edge_mask * diag_mask                      # {0,-1,-2}
+        out['edge_mask'] = edge_mask.view(batch_size * n_nodes * n_nodes, 1)
+
+    for key in const.DATA_ATTRS_TO_ADD_LAST_DIM:
+        if key in out.keys():
+            out[key] = out[key][:, :, None]
+    return out
+
+
+def create_template(tensor, fragment_size, linker_size, fill=0):
+    """Keep the fragment rows, append ``linker_size`` constant rows (datasets.py:476-480)."""
+    keep = tensor[:fragment_size]
+    add = torch.full((int(linker_size), tensor.shape[1]), fill, dtype=keep.dtype, device=keep.device)
+    return torch.cat([keep, add], dim=0)
+
+
+def create_templates_for_linker_generation(data, linker_sizes):
+    """Replace every molecule's linker rows by a zero template of the requested size
+    and re-collate (datasets.py:483-512)."""
+    decoupled = []
+    for i, linker_size in enumerate(linker_sizes):
+        item = {}
+        fragment_size = data['fragment_mask'][i].squeeze().sum().int()
+        for k, v in data.items():
+            if k == 'num_atoms':
+                item[k] = fragment_size + linker_size
+            elif k in const.DATA_LIST_ATTRS:
+                item[k] = v[i]
+            elif k in const.DATA_ATTRS_TO_PAD:
+                t = create_template(v[i], fragment_size, linker_size, fill=1 if k == 'linker_mask' else 0)
+                if k in const.DATA_ATTRS_TO_ADD_LAST_DIM:
+                    t = t.squeeze(-1)
+                item[k] = t
+        decoupled.append(item)
+    return collate(decoupled)

@@ -1,0 +1,174 @@
+"""Generate the golden fixtures in this directory from the UNMODIFIED reference.
+
+Run in the build container only (it imports /root/reference, which does not exist on the
+GPU box):   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Each fixture stores inputs + the reference's outputs; the weights are NOT stored, they are
+regenerated from a numpy seed by ``tests/helpers.seeded_state_dict`` and loaded into the
+reference modules here with ``load_state_dict(strict=True)``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, '/root/reference')
+sys.dont_write_bytecode = True
+
+from src import utils as ref_utils                      # noqa: E402
+from src.egnn import Dynamics, DynamicsWithPockets      # noqa: E402
+from src.edm import EDM                                 # noqa: E402
+from src.noise import PredefinedNoiseSchedule           # noqa: E402
+
+from helpers import seeded_state_dict                   # noqa: E402
+from difflinker_amd import synthetic                    # noqa: E402
+from difflinker_amd.datasets import collate             # noqa: E402
+
+
+def save(name, **arrays):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('wrote', name, {k: v.shape for k, v in out.items()})
+
+
+def ref_dynamics(cls, nf, ctx, n_layers, graph_type, seed, coord_gain=0.02):
+    dyn = cls(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, device='cpu', n_layers=n_layers,
+              attention=False, tanh=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False,
+              normalization_factor=100, aggregation_method='sum', model='egnn_dynamics',
+              normalization='batch_norm', centering=False, graph_type=graph_type)
+    sd = seeded_state_dict(nf + ctx + 1, 128, n_layers, seed, coord_gain=coord_gain)
+    dyn.load_state_dict(sd, strict=True)
+    return dyn.eval()
+
+
+def gamma_tables():
+    g500 = PredefinedNoiseSchedule('polynomial_2', timesteps=500, precision=1e-5).gamma.data
+    g1000 = PredefinedNoiseSchedule('polynomial_2', timesteps=1000, precision=1e-5).gamma.data
+    save('gamma_tables', g500=g500, g1000=g1000)
+
+
+def ragged_fc_batch(sizes, linkers, nf, seed):
+    g = torch.Generator().manual_seed(seed)
+    mols = []
+    for n, nl in zip(sizes, linkers):
+        frag = torch.zeros(n)
+        frag[:n - nl] = 1
+        types = torch.randint(0, nf, (n,), generator=g)
+        mols.append({'positions': 2.0 * torch.randn((n, 3), generator=g),
+                     'one_hot': torch.nn.functional.one_hot(types, nf).float(),
+                     'anchors': torch.zeros(n), 'fragment_mask': frag, 'linker_mask': 1 - frag,
+                     'num_atoms': n, 'uuid': 0, 'name': 'm'})
+    return collate(mols)
+
+
+@torch.no_grad()
+def fc_forward():
+    """Dynamics.forward, GEOM-like hparams, 2 blocks, ragged B=4 N=14, per-sample t."""
+    nf, ctx, L = 9, 1, 2
+    data = ragged_fc_batch([14, 9, 12, 5], [4, 3, 5, 2], nf, seed=11)
+    inp = synthetic.sampler_inputs(data)
+    g = torch.Generator().manual_seed(12)
+    B, N = inp['x'].shape[:2]
+    # a mid-chain state: fragments as given, linker rows noisy
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.randn((B, N, 3 + nf), generator=g) * inp['linker_mask']
+    t = torch.rand((B, 1), generator=g)
+    dyn = ref_dynamics(Dynamics, nf, ctx, L, 'FC', seed=21)
+    out = dyn.forward(t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'],
+                      edge_mask=inp['edge_mask'], context=inp['context'])
+    # the B=1 / scalar-t branch (egnn.py:397-399) on molecule 1, un-padded
+    n1 = 9
+    em1 = data['edge_mask'].view(B, N, N)[1, :n1, :n1].reshape(-1, 1)
+    out1 = dyn.forward(t=t[1:2], xh=z[1:2, :n1], node_mask=inp['node_mask'][1:2, :n1],
+                       linker_mask=inp['linker_mask'][1:2, :n1], edge_mask=em1, context=inp['context'][1:2, :n1])
+    save('fc_forward', nf=nf, ctx=ctx, n_layers=L, weight_seed=21, coord_gain=0.02,
+         t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'],
+         context=inp['context'], out=out, out_mol1_unpadded=out1)
+
+
+@torch.no_grad()
+def fc_chain():
+    """EDM.sample_chain, ZINC-like hparams, 2 blocks, T=12 on a 500-entry gamma table, shared noise bank."""
+    nf, ctx, L, T, keep = 8, 1, 2, 12, 3
+    data = ragged_fc_batch([12, 7, 10], [4, 2, 3], nf, seed=31)
+    inp = synthetic.sampler_inputs(data)
+    B, N = inp['x'].shape[:2]
+    g = torch.Generator().manual_seed(32)
+    draws = []
+    for _ in range(T + 2):
+        draws.append(torch.randn((B, N, 3), generator=g))
+        draws.append(torch.randn((B, N, nf), generator=g))
+    pos = [0]
+
+    def banked(size, device, node_mask):
+        d = draws[pos[0]]
+        assert tuple(d.shape) == tuple(size)
+        pos[0] += 1
+        return d * node_mask
+
+    dyn = ref_dynamics(Dynamics, nf, ctx, L, 'FC', seed=22)
+    edm = EDM(dynamics=dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+              noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
+    edm.T = T                                             # generate.py:103-104
+    orig = ref_utils.sample_gaussian_with_mask
+    ref_utils.sample_gaussian_with_mask = banked
+    try:
+        chain = edm.sample_chain(x=inp['x'], h=inp['h'], node_mask=inp['node_mask'],
+                                 fragment_mask=inp['fragment_mask'], linker_mask=inp['linker_mask'],
+                                 edge_mask=inp['edge_mask'], context=inp['context'], keep_frames=keep)
+    finally:
+        ref_utils.sample_gaussian_with_mask = orig
+    assert pos[0] == 2 * (T + 2)
+    save('fc_chain', nf=nf, ctx=ctx, n_layers=L, T=T, keep_frames=keep, weight_seed=22, coord_gain=0.02,
+         x=inp['x'], h=inp['h'], node_mask=inp['node_mask'], fragment_mask=inp['fragment_mask'],
+         linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'], context=inp['context'],
+         noise_x=torch.stack(draws[0::2]), noise_h=torch.stack(draws[1::2]), chain=chain)
+
+
+@torch.no_grad()
+def pocket_forward():
+    """DynamicsWithPockets.forward, FC-10A-4A, 2 blocks, B=2 (8 fragment + 24 pocket + linker atoms)."""
+    nf, ctx, L = 9, 2, 2
+    mols = synthetic.pocket_molecules(2, n_frag=8, n_pocket=24, linker=(3, 6), nf=nf, seed=41)
+    data = collate(mols)
+    inp = synthetic.sampler_inputs(data, pockets=True)
+    B, N = inp['x'].shape[:2]
+    g = torch.Generator().manual_seed(42)
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.cat([2.0 * torch.randn((B, N, 3), generator=g), torch.randn((B, N, nf), generator=g)], dim=2) \
+        * inp['linker_mask']
+    t = torch.rand((B, 1), generator=g)
+    dyn = ref_dynamics(DynamicsWithPockets, nf, ctx, L, 'FC-10A-4A', seed=23)
+    out = dyn.forward(t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'],
+                      edge_mask=inp['edge_mask'], context=inp['context'])
+    nm = inp['node_mask'].view(B * N, 1)
+    x = (z.view(B * N, -1) * nm)[:, :3]
+    edges = dyn.get_dist_edges(x, nm, inp['edge_mask'], inp['linker_mask'].view(B * N, 1),
+                               inp['context'][..., -2].reshape(B * N, 1), inp['context'][..., -1].reshape(B * N, 1))
+    save('pocket_forward', nf=nf, ctx=ctx, n_layers=L, weight_seed=23, coord_gain=0.02,
+         t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'],
+         context=inp['context'], out=out, edges=edges)
+
+
+@torch.no_grad()
+def collate_masks():
+    """int8 mask semantics of the reference collate (datasets.py:366-369): ~eye on int8."""
+    atom_mask = torch.tensor([[1, 1, 1, 0], [1, 1, 0, 0]], dtype=torch.int8)
+    edge_mask = atom_mask[:, None, :] * atom_mask[:, :, None]
+    diag = ~torch.eye(4, dtype=torch.int8).unsqueeze(0)
+    edge_mask *= diag
+    save('collate_masks', atom_mask=atom_mask, edge_mask=edge_mask.view(-1, 1))
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    gamma_tables()
+    collate_masks()
+    fc_forward()
+    fc_chain()
+    pocket_forward()
