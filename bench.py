@@ -1,0 +1,178 @@
+"""bench.py — molecules/s of the full 500-step ``sample_chain`` (BASELINE.json metric) on N MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``)
+
+A "step" is one complete ``EDM.sample_chain`` over one synthetic batch: T = 500 reverse steps + the
+final decode = 501 EGNN forwards, per GPU the workload of BASELINE config C2 (GEOM hparams, 6 blocks,
+B = 256 molecules padded to N = 50, n_b ~ U{35..50}).  Weak scaling: every rank samples its own 256
+molecules (global batch 256*N, config C3 at N = 8); no data-path collective, one all-gather of the
+final frame (RCCL over xGMI) inside the timed region.  Inputs are resident in HBM before the timed
+region; the noise draws (reference ``torch.randn`` call sequence) are part of the step.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     — fp32-MFMA roofline of the dominant kernel (``sample_chain_fc_kernel``): algorithmic
+                 FLOPs (SURVEY 8d F_min x 501 forwards) / live HIP-event duration of the launch
+  cpu_baseline — the oracle (PyTorch-CPU port of the reference path) timed on this box's host cores
+                 on a bounded sample (2 forwards of the same batch, extrapolated x501).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2'])
+    ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
+    ap.add_argument('--T', type=int, default=None, help='reverse steps (default: the config\'s, 500 for C2)')
+    ap.add_argument('--uniform-size', action='store_true', help='unpadded variant: every molecule has N atoms')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-forwards', type=int, default=2)
+    return ap.parse_args()
+
+
+def build_model(cfg, device):
+    from difflinker_amd import Dynamics, EDM
+    torch.manual_seed(0)                                   # random-init weights of the named architecture
+    dyn = Dynamics(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128,
+                   n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm')
+    edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+              noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
+    edm.T = cfg['T']
+    return edm.to(device)
+
+
+def cpu_baseline(edm, cfg, inp, n_forwards):
+    """Oracle = PyTorch-CPU port of the reference path, all host cores, bounded sample."""
+    from oracle import egnn_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in edm.dynamics.state_dict().items()}
+    ocfg = egnn_oracle.EGNNConfig(in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], n_layers=cfg['n_layers'])
+    B, N = inp['x'].shape[:2]
+    g = torch.Generator().manual_seed(1)
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.randn((B, N, 3 + cfg['nf']), generator=g) * inp['linker_mask']
+    t = torch.full((B, 1), 0.5)
+    args = (sd, ocfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    with torch.no_grad():
+        egnn_oracle.dynamics_forward(*args)                # warm-up (edge list, allocator)
+        t0 = time.perf_counter()
+        for _ in range(n_forwards):
+            egnn_oracle.dynamics_forward(*args)
+        dt = (time.perf_counter() - t0) / n_forwards
+    chain_s = dt * (cfg['T'] + 1)
+    return {'value': B / chain_s, 'unit': 'molecules/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_forwards} Dynamics.forward calls of the same batch (B={B}, N={N}, L={cfg["n_layers"]}) after 1 '
+                      f'warm-up, {dt:.2f} s each, extrapolated linearly to T+1={cfg["T"] + 1} forwards',
+            's_per_forward': dt}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == a.gpus or (a.gpus == 1 and world == 1), f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    import __graft_entry__ as entry
+    entry.build()
+    from difflinker_amd import synthetic
+    from difflinker_amd.distributed import all_gather_frames
+
+    data, cfg = synthetic.make_batch(a.config, seed=1000 + rank, batch=a.batch, uniform_size=a.uniform_size)
+    if a.T is not None:
+        cfg['T'] = a.T
+    inp_cpu = synthetic.sampler_inputs(data)
+    inp = {k: v.to(device) for k, v in inp_cpu.items()}    # inputs resident in HBM before the timed region
+    B, N = inp['x'].shape[:2]
+    edm = build_model(cfg, device)
+    edm.profile_events = True
+    pairs, nodes = synthetic.pair_and_node_counts(data)
+    fin = cfg['nf'] + cfg['ctx'] + 1
+    flops_fwd = synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes)
+
+    def one_chain():
+        chain = edm.sample_chain(keep_frames=1, **inp)
+        if world > 1:
+            chain = all_gather_frames(chain, B * world)    # only the final frame crosses GPUs
+        return chain
+
+    torch.manual_seed(1234 + rank)
+    for _ in range(a.warmup):
+        one_chain()
+    kernel_ms = []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        one_chain()
+        kernel_ms.append(edm.last_kernel_events)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    k_ms = [s.elapsed_time(e) for s, e in kernel_ms]
+    k_avg_ms = sum(k_ms) / len(k_ms)
+
+    if rank == 0:
+        achieved = flops_fwd * (cfg['T'] + 1) / (k_avg_ms * 1e-3) / 1e12
+        layer_bytes = synthetic.layer_bytes(nodes, pairs)
+        t_layer = k_avg_ms * 1e-3 / ((cfg['T'] + 1) * cfg['n_layers'])
+        out = {
+            'metric': 'molecules/sec (500-step sample_chain)', 'value': B * world * a.steps / elapsed,
+            'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{a.config}: GEOM geom_difflinker hparams (egnn_dynamics, hidden 128, '
+                                   f'{cfg["n_layers"]} blocks), batch={B} molecules/GPU padded to N={N} '
+                                   f'(n_b {"= N" if a.uniform_size else "~ U{35..50}"}), T={cfg["T"]} reverse steps '
+                                   f'+ decode = {cfg["T"] + 1} EGNN forwards per step; random-init weights, synthetic '
+                                   f'fragment graphs',
+                       'global_batch': B * world, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}',
+                       'real_pairs_per_forward': pairs, 'real_atoms': nodes},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'kernel': 'sample_chain_fc_kernel', 'kernel_ms': k_avg_ms,
+                         'flops_per_launch': flops_fwd * (cfg['T'] + 1)},
+            'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                          'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
+                          'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the fused '
+                                  'kernel is fp32-MFMA-bound, HBM fraction is expected << 1 %'},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(edm, cfg, inp_cpu, a.cpu_forwards)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

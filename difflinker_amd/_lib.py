@@ -1,0 +1,100 @@
+"""ctypes binding of ``libdifflinker_hip.so`` (C ABI declared in ``include/difflinker_hip.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc --offload-arch=gfx950``).
+There is deliberately NO fallback: if the shared object is missing or cannot be loaded every
+compute entry point of the package raises, it never routes to a CPU/PyTorch implementation.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads PyTorch-ROCm's libamdhip64 first so both share one HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdifflinker_hip.so')
+
+DL_OK = 0
+DL_ERR_TOO_MANY_ATOMS = -3
+
+
+class DLConfig(ctypes.Structure):
+    _fields_ = [
+        ('n_dims', ctypes.c_int32), ('in_node_nf', ctypes.c_int32), ('context_node_nf', ctypes.c_int32),
+        ('hidden_nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('inv_sublayers', ctypes.c_int32),
+        ('condition_time', ctypes.c_int32), ('norm_constant', ctypes.c_float),
+        ('normalization_factor', ctypes.c_float),
+    ]
+
+
+class DLStepCoef(ctypes.Structure):
+    _fields_ = [('t', ctypes.c_float), ('alpha_ts', ctypes.c_float), ('c_eps', ctypes.c_float),
+                ('sigma', ctypes.c_float)]
+
+
+class DLChainArgs(ctypes.Structure):
+    _fields_ = [
+        ('B', ctypes.c_int32), ('N', ctypes.c_int32), ('T', ctypes.c_int32), ('keep_frames', ctypes.c_int32),
+        ('x', ctypes.c_void_p), ('h', ctypes.c_void_p), ('node_mask', ctypes.c_void_p),
+        ('fragment_mask', ctypes.c_void_p), ('linker_mask', ctypes.c_void_p), ('edge_mask', ctypes.c_void_p),
+        ('context', ctypes.c_void_p), ('noise_x', ctypes.c_void_p), ('noise_h', ctypes.c_void_p),
+        ('coefs', ctypes.c_void_p),
+        ('inv_alpha0', ctypes.c_float), ('sigma0', ctypes.c_float), ('sigma_x', ctypes.c_float),
+        ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float),
+        ('chain', ctypes.c_void_p), ('nan_flags', ctypes.c_void_p), ('nan_step', ctypes.c_void_p),
+    ]
+
+
+EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_string', 'dl_model_num_tensors',
+           'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc')
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises ``HipLibraryError`` when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f'{LIB_PATH} not found: build the HIP extension first '
+            '(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.')
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise HipLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+    vp, i32 = ctypes.c_void_p, ctypes.c_int32
+    lib.dl_abi_version.restype = i32
+    lib.dl_last_hip_error.restype = i32
+    lib.dl_max_atoms.restype = i32
+    lib.dl_error_string.restype = ctypes.c_char_p
+    lib.dl_error_string.argtypes = [i32]
+    lib.dl_model_num_tensors.restype = i32
+    lib.dl_model_num_tensors.argtypes = [ctypes.POINTER(DLConfig)]
+    lib.dl_model_create.restype = i32
+    lib.dl_model_create.argtypes = [ctypes.POINTER(DLConfig), ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]
+    lib.dl_model_destroy.restype = None
+    lib.dl_model_destroy.argtypes = [vp]
+    lib.dl_egnn_forward_fc.restype = i32
+    lib.dl_egnn_forward_fc.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.dl_sampler_step.restype = i32
+    lib.dl_sampler_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, DLStepCoef, vp, vp]
+    lib.dl_sample_chain_fc.restype = i32
+    lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != DL_OK:
+        lib = load()
+        msg = lib.dl_error_string(status).decode()
+        raise HipLibraryError(f'{what}: {msg} (status {status}, hip error {lib.dl_last_hip_error()})')
+
+
+def ptr(t):
+    """Device/host pointer of a tensor (or NULL for None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

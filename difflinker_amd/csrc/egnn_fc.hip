@@ -1,0 +1,883 @@
+// egnn_fc.hip — MI355X (gfx950, CDNA4) kernels for DiffLinker's EGNN denoiser on fully-connected
+// molecular graphs, and the fused ancestral-sampling chain built on it.
+//
+// Reference behaviour (file:line into igashov/DiffLinker): Dynamics.forward src/egnn.py:374-447,
+// EGNN.forward :218-238, EquivariantBlock :157-178, GCL :45-80, EquivariantUpdate :101-125,
+// coord2diff :295-301, unsorted_segment_sum :304-320, EDM.sample_chain src/edm.py:126-242.
+//
+// Design:
+//   * one 512-thread workgroup (8 wave64) per molecule; the molecule's whole EGNN state lives in
+//     LDS for the entire forward (or the entire T-step chain): per-atom first-layer projections
+//     P,Q [n,128], the message aggregate / node features [n,128], coordinates, masks.
+//   * the O(n^2) edge pass never materialises an edge tensor: each wave takes tiles of 32 (i,j)
+//     pairs, generates the first-layer activations SiLU(P_i + Q_j + r*w_r + d0*w_d) straight into
+//     MFMA A-fragments, multiplies by the 128x128 second-layer weights (LDS-resident, 64 KB) with
+//     v_mfma_f32_32x32x2_f32 (exact fp32), applies SiLU + edge mask in the accumulator layout and
+//     reduces over j with LDS float atomics (GCL) or a 32-lane butterfly (coordinate head).
+//   * per-node GEMMs (first-layer projections, node MLP) run on the same MFMA with the atom index
+//     as the M dimension; their weights stream from L2 in a pre-packed fragment order.
+//   * SiLU is evaluated as y * rcp(1 + exp2(y)) with y = -log2(e) * pre-activation; the constant is
+//     folded into the packed weights on the host (dl_model_create), so the device does one v_exp_f32
+//     and one v_rcp_f32 per activation.
+//   * no HBM traffic inside a forward besides the (L2-resident) weights: inputs are read once,
+//     eps_hat written once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "../../include/difflinker_hip.h"
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int HID = 128;            // hidden_nf
+constexpr int LDH = 132;            // LDS row stride of [n,128] fp32 tiles: 528 B = 33 x 16 B (conflict-free b128)
+constexpr int NMAX = 55;            // real atoms per molecule that fit the LDS-resident layout
+constexpr int UNIT = HID * HID;     // one packed 128x128 matrix
+constexpr int FINP = 16;            // embedding input width, padded
+constexpr int DMAX = 16;            // row stride of the per-atom state z = [x(3), h(nf)], 3+nf <= 16
+constexpr int CTXMAX = 4;
+constexpr int THREADS = 512;
+constexpr int NWAVES = 8;
+
+// ---- packed weight buffer (floats); mirrored by pack_model() below -------------------------------
+constexpr int OFF_EMB_W = 0;                          // [128][FINP]
+constexpr int OFF_EMB_B = OFF_EMB_W + HID * FINP;     // [128]
+constexpr int OFF_OUT_W = OFF_EMB_B + HID;            // [16][128]
+constexpr int OFF_OUT_B = OFF_OUT_W + 16 * HID;       // [16]
+constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
+// GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image), vectors
+constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT;
+constexpr int G_VEC = 6 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
+constexpr int GCL_SIZE = 6 * UNIT + 6 * HID;
+// equivariant update: units W5a', W5b', W6' (LDS image), vectors
+constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT;
+constexpr int E_VEC = 3 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
+constexpr int EQ_SIZE = 3 * UNIT + 5 * HID;
+constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
+
+// ---- LDS layout (floats) ---------------------------------------------------------------------------
+constexpr int L_A = 0;                                // P  / h row-major / eps (aliased at the end)
+constexpr int L_B = L_A + NMAX * LDH;                 // Q  / node-MLP hidden
+constexpr int L_C = L_B + NMAX * LDH;                 // H (node features) / message aggregate
+constexpr int L_W = L_C + NMAX * LDH;                 // 128x128 second-layer weights, [k][c][nt]
+constexpr int L_VEC = L_W + UNIT;                     // wr', wd', b2'|b6', w7'
+constexpr int L_XS = L_VEC + 4 * HID;                 // current coordinates [n][4]
+constexpr int L_X0 = L_XS + NMAX * 4;                 // coordinates at forward entry [n][4]
+constexpr int L_AGGX = L_X0 + NMAX * 4;               // coordinate aggregate [n][4]
+constexpr int L_Z = L_AGGX + NMAX * 4;                // per-atom state z [n][DMAX]
+constexpr int L_LM = L_Z + NMAX * DMAX;               // linker mask [n]
+constexpr int L_FRAG = L_LM + 56;                     // fragment mask [n]
+constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padded position [n] (int)
+constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
+constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
+constexpr int L_TOTAL = L_MISC + 16;
+constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
+static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
+static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
+              (L_X0 % 4) == 0 && (L_AGGX % 4) == 0 && (L_Z % 4) == 0 && (L_CTX % 4) == 0, "16-byte alignment");
+
+struct Lds {
+    float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag, *ctx;
+    int *idx, *misc;
+};
+
+__device__ __forceinline__ Lds lds_view(float* base) {
+    Lds v;
+    v.A = base + L_A; v.B = base + L_B; v.C = base + L_C; v.W = base + L_W; v.vec = base + L_VEC;
+    v.xs = base + L_XS; v.x0 = base + L_X0; v.aggx = base + L_AGGX; v.z = base + L_Z;
+    v.lm = base + L_LM; v.frag = base + L_FRAG; v.ctx = base + L_CTX;
+    v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
+    return v;
+}
+
+struct ModelDims {
+    int nf, ctx, fin, n_layers;
+    float norm_constant;
+};
+
+// u = y * sigmoid(-y / log2e)  ==  -log2(e) * SiLU(pre)  for  y = -log2(e) * pre
+__device__ __forceinline__ float silu_u(float y) {
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+}
+
+__device__ __forceinline__ floatx16 splat16(float v) {
+    floatx16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = v;
+    return r;
+}
+
+__device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.
+// A: LDS row `arow` of a [n][LDH] tile; this lane supplies k = 64*hh + s.
+// B: packed unit slice for one 32-feature tile, fragment order [sg][lane][4] (L2-resident).
+__device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh,
+                                          const float* __restrict__ unit_nt, int lane) {
+    const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
+    const float4* bp = reinterpret_cast<const float4*>(unit_nt) + lane;
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) {
+        const float4 a = ap[sg];
+        const float4 b = bp[sg * 64];
+        acc = mfma32(a.x, b.x, acc);
+        acc = mfma32(a.y, b.y, acc);
+        acc = mfma32(a.z, b.z, acc);
+        acc = mfma32(a.w, b.w, acc);
+    }
+}
+
+// copy the [k][c][nt] image of a 128x128 matrix and `nvec` 128-vectors from L2 into LDS
+__device__ __forceinline__ void stage_edge_weights(const Lds& v, const float* __restrict__ wimg,
+                                                   const float* __restrict__ vecs, int nvec, int tid) {
+    const float4* src = reinterpret_cast<const float4*>(wimg);
+    float4* dst = reinterpret_cast<float4*>(v.W);
+#pragma unroll
+    for (int it = 0; it < UNIT / 4 / THREADS; ++it) dst[it * THREADS + tid] = src[it * THREADS + tid];
+    if (tid < nvec * HID / 4)
+        reinterpret_cast<float4*>(v.vec)[tid] = reinterpret_cast<const float4*>(vecs)[tid];
+}
+
+// P[a][f] = b1'[f] + sum_k W1a'[f][k] H[a][k]  -> v.A ;  Q[a][f] = sum_k W1b'[f][k] H[a][k] -> v.B
+__device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, const float* __restrict__ unit_a,
+                                         const float* __restrict__ unit_b, const float* __restrict__ bias) {
+    const int c = lane & 31, hh = lane >> 5;
+    const int nt = w & 3;
+    const bool isP = w < 4;
+    const float* unit = (isP ? unit_a : unit_b) + nt * (UNIT / 4);
+    float* dst = isP ? v.A : v.B;
+    const float b = isP ? bias[32 * nt + c] : 0.0f;
+    const int mtiles = nb > 32 ? 2 : 1;
+    for (int mt = 0; mt < mtiles; ++mt) {
+        floatx16 acc = splat16(b);
+        const int arow = min(32 * mt + c, nb - 1);
+        gemm_k128(acc, v.C, arow, hh, unit, lane);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + acc_row(reg, hh);
+            if (row < nb) dst[row * LDH + 32 * nt + c] = acc[reg];
+        }
+    }
+}
+
+// One pass over all n_b^2 ordered pairs of the molecule.
+//   EQUIV = false: agg[i][f] += m_ij * u2_ij[f]           (GCL message sum, into v.C)
+//   EQUIV = true : aggx[i]   += cdiff_ij * (w7'.u2_ij) * m_ij (coordinate head, into v.aggx)
+template <bool EQUIV>
+__device__ __forceinline__ void edge_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask,
+                                           int N, float norm_constant) {
+    const int c = lane & 31, hh = lane >> 5;
+    const int npairs = nb * nb;
+    const int ntiles = (npairs + 31) >> 5;
+    float bias[4], w7[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        bias[nt] = v.vec[2 * HID + 32 * nt + c];
+        w7[nt] = EQUIV ? v.vec[3 * HID + 32 * nt + c] : 0.0f;
+    }
+    const float4* wrp = reinterpret_cast<const float4*>(v.vec + 64 * hh);
+    const float4* wdp = reinterpret_cast<const float4*>(v.vec + HID + 64 * hh);
+    const float4* Wp = reinterpret_cast<const float4*>(v.W) + (64 * hh * 32 + c);
+
+    for (int t = w; t < ntiles; t += NWAVES) {
+        const int p = 32 * t + c;
+        const bool valid = p < npairs;
+        const int pp = valid ? p : 0;
+        const int i = pp / nb;
+        const int j = pp - i * nb;
+        const float4 xi = *reinterpret_cast<const float4*>(v.xs + 4 * i);
+        const float4 xj = *reinterpret_cast<const float4*>(v.xs + 4 * j);
+        const float4 yi = *reinterpret_cast<const float4*>(v.x0 + 4 * i);
+        const float4 yj = *reinterpret_cast<const float4*>(v.x0 + 4 * j);
+        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
+        const float r = dx * dx + dy * dy + dz * dz;             // squared distance, current x  (egnn.py:298)
+        const float d0 = ex * ex + ey * ey + ez * ez;            // squared distance at forward entry (:220)
+        float m = 0.0f;
+        if (valid) m = emask ? float(emask[v.idx[i] * N + v.idx[j]]) : 1.0f;
+
+        // ---- first edge layer, generated directly as MFMA A-fragments: lane = (pair c, k = 64*hh + s)
+        float a[64];
+        {
+            const float4* Pp = reinterpret_cast<const float4*>(v.A + i * LDH + 64 * hh);
+            const float4* Qp = reinterpret_cast<const float4*>(v.B + j * LDH + 64 * hh);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
+                a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
+                a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
+                a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
+                a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+            }
+        }
+        // ---- second edge layer: [32 pairs x 128] = A[32 x 128] * W2'^T, 4 feature tiles, exact fp32 MFMA
+        floatx16 acc0 = splat16(bias[0]), acc1 = splat16(bias[1]), acc2 = splat16(bias[2]), acc3 = splat16(bias[3]);
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float4 b = Wp[s * 32];
+            acc0 = mfma32(a[s], b.x, acc0);
+            acc1 = mfma32(a[s], b.y, acc1);
+            acc2 = mfma32(a[s], b.z, acc2);
+            acc3 = mfma32(a[s], b.w, acc3);
+        }
+        // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
+        if (!EQUIV) {
+            const int i_first = __builtin_amdgcn_readfirstlane(i);
+            const bool two_rows = __all(!valid || i <= i_first + 1);
+            if (two_rows) {
+                // all pairs of the tile belong to atom i_first or i_first+1: pre-reduce in registers
+                float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = acc_row(reg, hh);
+                    const float mr = __shfl(m, row);
+                    const int ir = __shfl(i, row);
+                    const float m0 = (ir == i_first) ? mr : 0.0f;
+                    const float m1 = mr - m0;
+                    const float u0 = silu_u(acc0[reg]), u1 = silu_u(acc1[reg]);
+                    const float u2 = silu_u(acc2[reg]), u3 = silu_u(acc3[reg]);
+                    s0[0] = fmaf(m0, u0, s0[0]); s1[0] = fmaf(m1, u0, s1[0]);
+                    s0[1] = fmaf(m0, u1, s0[1]); s1[1] = fmaf(m1, u1, s1[1]);
+                    s0[2] = fmaf(m0, u2, s0[2]); s1[2] = fmaf(m1, u2, s1[2]);
+                    s0[3] = fmaf(m0, u3, s0[3]); s1[3] = fmaf(m1, u3, s1[3]);
+                }
+                float* d0p = v.C + i_first * LDH + c;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) atomicAdd(d0p + 32 * nt, s0[nt]);
+                if (i_first + 1 < nb) {
+                    float* d1p = d0p + LDH;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) atomicAdd(d1p + 32 * nt, s1[nt]);
+                }
+            } else {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = acc_row(reg, hh);
+                    const float mr = __shfl(m, row);
+                    const int ir = __shfl(i, row);
+                    float* dst = v.C + ir * LDH + c;
+                    atomicAdd(dst, mr * silu_u(acc0[reg]));
+                    atomicAdd(dst + 32, mr * silu_u(acc1[reg]));
+                    atomicAdd(dst + 64, mr * silu_u(acc2[reg]));
+                    atomicAdd(dst + 96, mr * silu_u(acc3[reg]));
+                }
+            }
+        } else {
+            // s_row = sum_f w7'[f] * u2[row][f]: 4 in-lane terms, then a butterfly over the 32 lanes of the half
+            float srow[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float ts = w7[0] * silu_u(acc0[reg]);
+                ts = fmaf(w7[1], silu_u(acc1[reg]), ts);
+                ts = fmaf(w7[2], silu_u(acc2[reg]), ts);
+                ts = fmaf(w7[3], silu_u(acc3[reg]), ts);
+                ts += __shfl_xor(ts, 16);
+                ts += __shfl_xor(ts, 8);
+                ts += __shfl_xor(ts, 4);
+                ts += __shfl_xor(ts, 2);
+                ts += __shfl_xor(ts, 1);
+                srow[reg] = ts;
+            }
+            // lane c owns pair c = row c: fetch its scalar from the half/register that holds row c
+            const int src_lane = 32 * ((c >> 2) & 1);
+            const int my_reg = (c & 3) + 4 * (c >> 3);
+            float s_own = 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float vv = __shfl(srow[reg], src_lane);
+                s_own = (reg == my_reg) ? vv : s_own;
+            }
+            if (hh == 0 && valid) {
+                // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
+                const float den = sqrtf(r + 1e-8f) + norm_constant;
+                const float f = s_own * m;
+                atomicAdd(v.aggx + 4 * i + 0, (dx / den) * f);
+                atomicAdd(v.aggx + 4 * i + 1, (dy / den) * f);
+                atomicAdd(v.aggx + 4 * i + 2, (dz / den) * f);
+            }
+        }
+    }
+}
+
+// GCL (egnn.py:45-80) on the LDS-resident molecule; `hown` is this wave's 32x32 tile of h in registers.
+__device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ g,
+                                         floatx16& hown, const int8_t* __restrict__ emask, int N) {
+    const int c = lane & 31, hh = lane >> 5;
+    const int nt = w & 3, mt = w >> 2;
+    const float* vecs = g + G_VEC;
+    stage_edge_weights(v, g + G_W2, vecs + HID, 3, tid);
+    node_pre(v, nb, w, lane, g + G_W1A, g + G_W1B, vecs);
+    __syncthreads();                       // P, Q, W2', vectors in place; every read of H (v.C) done
+    for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
+    __syncthreads();
+    edge_phase<false>(v, nb, w, lane, emask, N, 0.0f);
+    __syncthreads();                       // aggregate complete in v.C; P (v.A), Q (v.B) dead
+    const bool active = (mt == 0) || (nb > 32);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * mt + acc_row(reg, hh);
+        if (row < nb) v.A[row * LDH + 32 * nt + c] = hown[reg];
+    }
+    __syncthreads();
+    // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
+    if (active) {
+        floatx16 acc = splat16(vecs[4 * HID + 32 * nt + c]);
+        const int arow = min(32 * mt + c, nb - 1);
+        gemm_k128(acc, v.A, arow, hh, g + G_W3A + nt * (UNIT / 4), lane);
+        gemm_k128(acc, v.C, arow, hh, g + G_W3B + nt * (UNIT / 4), lane);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + acc_row(reg, hh);
+            if (row < nb) v.B[row * LDH + 32 * nt + c] = silu_u(acc[reg]);
+        }
+    }
+    __syncthreads();
+    // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
+    if (active) {
+        const float b4 = vecs[5 * HID + 32 * nt + c];
+        floatx16 acc;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[reg] = hown[reg] + b4;
+        const int arow = min(32 * mt + c, nb - 1);
+        gemm_k128(acc, v.B, arow, hh, g + G_W4 + nt * (UNIT / 4), lane);
+        hown = acc;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + acc_row(reg, hh);
+            if (row < nb) v.C[row * LDH + 32 * nt + c] = acc[reg];
+        }
+    }
+    __syncthreads();
+}
+
+// EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
+__device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ e,
+                                           const int8_t* __restrict__ emask, int N, float norm_constant) {
+    const float* vecs = e + E_VEC;
+    stage_edge_weights(v, e + E_W6, vecs + HID, 4, tid);
+    node_pre(v, nb, w, lane, e + E_W5A, e + E_W5B, vecs);
+    if (tid < 4 * nb) v.aggx[tid] = 0.0f;
+    __syncthreads();
+    edge_phase<true>(v, nb, w, lane, emask, N, norm_constant);
+    __syncthreads();
+    if (tid < 4 * nb && (tid & 3) < 3) v.xs[tid] += v.aggx[tid] * v.lm[tid >> 2];
+    __syncthreads();
+}
+
+// Dynamics.forward for the molecule resident in LDS: reads v.z (state), v.ctx, v.lm, time feature t;
+// writes eps_hat[a][0:3+nf] into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
+__device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, const ModelDims& md,
+                                                 const float* __restrict__ wp, float tfeat,
+                                                 const int8_t* __restrict__ emask, int N) {
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int c = lane & 31, hh = lane >> 5;
+    const int nt = w & 3, mt = w >> 2;
+
+    // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
+    if (tid < 4 * nb) {
+        const int a = tid >> 2, k = tid & 3;
+        const float xv = (k < 3) ? v.z[a * DMAX + k] : 0.0f;
+        v.xs[tid] = xv;
+        v.x0[tid] = xv;
+    }
+    // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224)
+    {
+        const int f = tid & (HID - 1);
+        float wrow[FINP];
+        const float4* wsrc = reinterpret_cast<const float4*>(wp + OFF_EMB_W + f * FINP);
+#pragma unroll
+        for (int q = 0; q < FINP / 4; ++q) {
+            const float4 t4 = wsrc[q];
+            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+        }
+        const float be = wp[OFF_EMB_B + f];
+        for (int a = tid >> 7; a < nb; a += THREADS / HID) {
+            float acc = be;
+#pragma unroll
+            for (int k = 0; k < FINP; ++k) {
+                float hin = 0.0f;
+                if (k < md.nf) hin = v.z[a * DMAX + 3 + k];
+                else if (k == md.nf) hin = tfeat;
+                else if (k < md.fin) hin = v.ctx[a * CTXMAX + (k - md.nf - 1)];
+                acc = fmaf(wrow[k], hin, acc);
+            }
+            v.C[a * LDH + f] = acc;
+        }
+    }
+    __syncthreads();
+    floatx16 hown;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = 32 * mt + acc_row(reg, hh);
+        hown[reg] = (row < nb) ? v.C[row * LDH + 32 * nt + c] : 0.0f;
+    }
+
+    for (int blk = 0; blk < md.n_layers; ++blk) {
+        const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
+#pragma nounroll
+        for (int gi = 0; gi < 2; ++gi) gcl_pass(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N);
+        equiv_pass(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant);
+    }
+
+    // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
+    float* eps = v.A;
+    int nanbits = 0;
+    for (int e = tid; e < nb * md.nf; e += THREADS) {
+        const int a = e / md.nf, o = e - a * md.nf;
+        const float4* hp = reinterpret_cast<const float4*>(v.C + a * LDH);
+        const float4* wo = reinterpret_cast<const float4*>(wp + OFF_OUT_W + o * HID);
+        float acc = wp[OFF_OUT_B + o];
+#pragma unroll 8
+        for (int q = 0; q < HID / 4; ++q) {
+            const float4 hv = hp[q], wv = wo[q];
+            acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc);
+            acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+        }
+        eps[a * DMAX + 3 + o] = acc;
+        if (acc != acc) nanbits |= 2;
+    }
+    if (tid < 4 * nb && (tid & 3) < 3) {
+        const float vel = v.xs[tid] - v.x0[tid];
+        eps[(tid >> 2) * DMAX + (tid & 3)] = vel;
+        if (vel != vel) nanbits |= 1;
+    }
+    if (nanbits) atomicOr(&v.misc[1], nanbits);
+    __syncthreads();
+}
+
+// compact the real atoms of molecule b: v.idx[0..n_b) = padded positions with node_mask != 0
+__device__ __forceinline__ int compact_atoms(const Lds& v, const int8_t* __restrict__ node_mask_b, int N, int tid) {
+    if (tid < 64) {
+        int count = 0;
+        for (int base = 0; base < N; base += 64) {
+            const int a = base + tid;
+            const bool real = (a < N) && (node_mask_b[a] != 0);
+            const unsigned long long bal = __ballot(real);
+            const int pos = count + __popcll(bal & ((1ull << tid) - 1ull));
+            if (real && pos < NMAX) v.idx[pos] = a;
+            count += __popcll(bal);
+        }
+        if (tid == 0) { v.misc[0] = count; v.misc[1] = 0; }
+    }
+    __syncthreads();
+    return v.misc[0];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel 1: one Dynamics.forward per launch (src/egnn.py:374-447), one workgroup per molecule.
+// ---------------------------------------------------------------------------------------------------
+struct FwdArgs {
+    const float* wpack;
+    ModelDims md;
+    int B, N;
+    const float* xh;
+    const float* t;
+    int t_stride;
+    const int8_t* node_mask;
+    const float* linker_mask;
+    const int8_t* edge_mask;
+    const float* context;
+    float* out;
+    int* nan_flags;
+};
+
+__global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const Lds v = lds_view(lds_raw);
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int N = p.N, D = 3 + p.md.nf;
+    const int8_t* nm = p.node_mask + size_t(b) * N;
+    float* out_b = p.out + size_t(b) * N * D;
+
+    const int nb = compact_atoms(v, nm, N, tid);
+    // padded rows of the output are exactly zero (node_mask multiply, egnn.py:420,236-237)
+    for (int e = tid; e < N * D; e += THREADS)
+        if (nm[e / D] == 0) out_b[e] = 0.0f;
+    if (nb > NMAX) {
+        for (int e = tid; e < N * D; e += THREADS) out_b[e] = 0.0f;
+        if (tid == 0) p.nan_flags[b] = 4;
+        return;
+    }
+    if (nb == 0) {
+        if (tid == 0) p.nan_flags[b] = 0;
+        return;
+    }
+    const float* xh_b = p.xh + size_t(b) * N * D;
+    for (int e = tid; e < nb * D; e += THREADS) {
+        const int a = e / D, d = e - a * D;
+        v.z[a * DMAX + d] = xh_b[v.idx[a] * D + d];
+    }
+    if (tid < nb) {
+        v.lm[tid] = p.linker_mask ? p.linker_mask[size_t(b) * N + v.idx[tid]] : 1.0f;
+        for (int k = 0; k < p.md.ctx; ++k)
+            v.ctx[tid * CTXMAX + k] = p.context[(size_t(b) * N + v.idx[tid]) * p.md.ctx + k];
+    }
+    __syncthreads();
+    const float tfeat = p.t[size_t(b) * p.t_stride];
+    const int8_t* em = p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr;
+    forward_molecule(v, nb, tid, p.md, p.wpack, tfeat, em, N);
+    for (int e = tid; e < nb * D; e += THREADS) {
+        const int a = e / D, d = e - a * D;
+        out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
+    }
+    if (tid == 0) p.nan_flags[b] = v.misc[1];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel 2: EDM.sample_chain (src/edm.py:126-242) — T reverse steps + final decode in ONE launch.
+// ---------------------------------------------------------------------------------------------------
+struct ChainArgs {
+    const float* wpack;
+    ModelDims md;
+    dl_chain_args a;
+};
+
+__global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    const Lds v = lds_view(lds_raw);
+    const dl_chain_args& g = p.a;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x;
+    const int N = g.N, nf = p.md.nf, D = 3 + nf, T = g.T, K = g.keep_frames, B = g.B;
+    const int8_t* nm = g.node_mask + size_t(b) * N;
+    const size_t frame = size_t(B) * N * D;
+    float* chain_b = g.chain + size_t(b) * N * D;
+
+    const int nb = compact_atoms(v, nm, N, tid);
+    if (tid == 0) { g.nan_flags[b] = (nb > NMAX) ? 4 : 0; g.nan_step[b] = -1; }
+    // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
+    for (int k = 0; k < K; ++k)
+        for (int e = tid; e < N * D; e += THREADS)
+            if (nm[e / D] == 0 || nb > NMAX) chain_b[k * frame + e] = 0.0f;
+    if (nb > NMAX || nb == 0) return;
+
+    if (tid < nb) {
+        const size_t n = size_t(b) * N + v.idx[tid];
+        v.lm[tid] = g.linker_mask[n];
+        v.frag[tid] = g.fragment_mask[n];
+        for (int k = 0; k < p.md.ctx; ++k) v.ctx[tid * CTXMAX + k] = g.context[n * p.md.ctx + k];
+    }
+    __syncthreads();
+    // z = normalize(x,h) * fragment_mask + noise_0 * linker_mask   (edm.py:132-137,347-350)
+    for (int e = tid; e < nb * D; e += THREADS) {
+        const int a = e / D, d = e - a * D;
+        const size_t n = size_t(b) * N + v.idx[a];
+        float val, eps0;
+        if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = g.noise_x[n * 3 + d]; }
+        else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = g.noise_h[n * nf + d - 3]; }
+        const float lm = v.lm[a];
+        v.z[a * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[a]), __fmul_rn(__fmul_rn(eps0, lm), lm));
+    }
+    __syncthreads();
+    const int8_t* em = g.edge_mask ? g.edge_mask + size_t(b) * N * N : nullptr;
+    const size_t nx_stride = size_t(B) * N * 3, nh_stride = size_t(B) * N * nf;
+
+    for (int q = 0; q <= T; ++q) {
+        const bool decode = (q == T);                          // last forward: p(x,h | z_0), edm.py:210-242
+        dl_step_coef cf;
+        if (decode) { cf.t = 0.0f; cf.alpha_ts = 1.0f; cf.c_eps = 0.0f; cf.sigma = 0.0f; }
+        else cf = g.coefs[q];
+        forward_molecule(v, nb, tid, p.md, p.wpack, cf.t, em, N);
+        if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
+            if (tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
+            return;
+        }
+        const int s = T - 1 - q;
+        const int widx = decode ? 0 : (s * K) / T;
+        const bool last_writer = (s == 0) || (((s - 1) * K) / T != widx);
+        const bool write = !decode && last_writer && widx != 0;   // frame 0 is overwritten by the decode
+        for (int e = tid; e < nb * D; e += THREADS) {
+            const int a = e / D, d = e - a * D;
+            const size_t n = size_t(b) * N + v.idx[a];
+            const float lm = v.lm[a];
+            const float zt = v.z[a * DMAX + d];
+            const float eh = __fmul_rn(v.A[a * DMAX + d], lm);
+            const float nz = (d < 3) ? g.noise_x[(q + 1) * nx_stride + n * 3 + d]
+                                     : g.noise_h[(q + 1) * nh_stride + n * nf + d - 3];
+            float zn;
+            if (!decode) {
+                // z_s = z_t*frag + (z_t/alpha - c_eps*(eps*lm) + sigma*(noise*lm))*lm   (edm.py:196-206)
+                const float mu = __fsub_rn(__fdiv_rn(zt, cf.alpha_ts), __fmul_rn(cf.c_eps, eh));
+                const float zs = __fadd_rn(mu, __fmul_rn(cf.sigma, __fmul_rn(nz, lm)));
+                zn = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(zs, lm));
+                if (write) {                                   // chain[widx] = unnormalize_z(z) (edm.py:162-163)
+                    const float o = (d < 3) ? __fmul_rn(zn, g.norm_x) : __fadd_rn(__fmul_rn(zn, g.norm_h), g.bias_h);
+                    chain_b[widx * frame + v.idx[a] * D + d] = o;
+                }
+            } else {
+                // xh = z_0*frag + (1/alpha_0*(z_0 - sigma_0*eps) + sigma_x*(noise*lm))*lm, then unnormalize
+                const float mu = __fmul_rn(g.inv_alpha0, __fsub_rn(zt, __fmul_rn(g.sigma0, eh)));
+                const float xh = __fadd_rn(mu, __fmul_rn(g.sigma_x, __fmul_rn(nz, lm)));
+                const float zz = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(xh, lm));
+                zn = (d < 3) ? __fmul_rn(zz, g.norm_x) : __fadd_rn(__fmul_rn(zz, g.norm_h), g.bias_h);
+            }
+            v.z[a * DMAX + d] = zn;
+        }
+        __syncthreads();
+    }
+    if (tid < nb) {
+        const int a = tid;
+        float* o = chain_b + v.idx[a] * D;
+        o[0] = v.z[a * DMAX + 0]; o[1] = v.z[a * DMAX + 1]; o[2] = v.z[a * DMAX + 2];
+        int best = 0;                                          // torch.argmax: first maximal index
+        float bv = v.z[a * DMAX + 3];
+        for (int k = 1; k < nf; ++k) {
+            const float hv = v.z[a * DMAX + 3 + k];
+            if (hv > bv) { bv = hv; best = k; }
+        }
+        for (int k = 0; k < nf; ++k) o[3 + k] = (k == best) ? 1.0f : 0.0f;   // one_hot * node_mask (=1 here)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernel 3: fused tail of one reverse step for callers that drive the loop from the host.
+// ---------------------------------------------------------------------------------------------------
+__global__ void sampler_step_kernel(int total, int D, const float* __restrict__ z_t, const float* __restrict__ eps_hat,
+                                    const float* __restrict__ noise, const float* __restrict__ frag,
+                                    const float* __restrict__ lmask, dl_step_coef cf, float* __restrict__ z_s) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= total) return;
+    const int n = e / D;
+    const float lm = lmask[n];
+    const float zt = z_t[e];
+    const float eh = __fmul_rn(eps_hat[e], lm);
+    const float mu = __fsub_rn(__fdiv_rn(zt, cf.alpha_ts), __fmul_rn(cf.c_eps, eh));
+    const float zs = __fadd_rn(mu, __fmul_rn(cf.sigma, __fmul_rn(noise[e], lm)));
+    z_s[e] = __fadd_rn(__fmul_rn(zt, frag[n]), __fmul_rn(zs, lm));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host side: weight packing and the C ABI
+// ---------------------------------------------------------------------------------------------------
+thread_local int g_last_hip = 0;
+
+inline bool hip_ok(hipError_t e) {
+    if (e != hipSuccess) { g_last_hip = int(e); return false; }
+    return true;
+}
+
+// node-fragment order: unit[nt][sg][lane][j] = W[f = 32nt + (lane&31)][k = 4sg + j + 64(lane>>5)]
+void pack_unit(float* dst, const float* w, int ld, int col0, double scale) {
+    for (int nt = 0; nt < 4; ++nt)
+        for (int sg = 0; sg < 16; ++sg)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 4; ++j) {
+                    const int f = 32 * nt + (lane & 31);
+                    const int k = 4 * sg + j + 64 * (lane >> 5);
+                    dst[((nt * 16 + sg) * 64 + lane) * 4 + j] = float(double(w[size_t(f) * ld + col0 + k]) * scale);
+                }
+}
+
+// LDS image: img[k][c][nt] = W[f = 32nt + c][k]
+void pack_lds_image(float* dst, const float* w, int ld, double scale) {
+    for (int k = 0; k < HID; ++k)
+        for (int c = 0; c < 32; ++c)
+            for (int nt = 0; nt < 4; ++nt)
+                dst[(k * 32 + c) * 4 + nt] = float(double(w[size_t(32 * nt + c) * ld + k]) * scale);
+}
+
+void pack_vec(float* dst, const float* src, int stride, double scale) {
+    for (int f = 0; f < HID; ++f) dst[f] = float(double(src[size_t(f) * stride]) * scale);
+}
+
+}  // namespace
+
+struct dl_model {
+    dl_config cfg;
+    float* d_pack;
+    size_t n_floats;
+};
+
+extern "C" {
+
+int32_t dl_abi_version(void) { return DL_ABI_VERSION; }
+int32_t dl_last_hip_error(void) { return g_last_hip; }
+int32_t dl_max_atoms(void) { return NMAX; }
+
+const char* dl_error_string(int32_t s) {
+    switch (s) {
+        case DL_OK: return "ok";
+        case DL_ERR_BAD_ARG: return "bad argument";
+        case DL_ERR_UNSUPPORTED: return "hyper-parameter not supported by the HIP path";
+        case DL_ERR_TOO_MANY_ATOMS: return "molecule exceeds dl_max_atoms()";
+        case DL_ERR_HIP: return "HIP runtime error";
+        case DL_ERR_NO_DEVICE: return "no HIP device";
+        case DL_ERR_ALLOC: return "allocation failed";
+        default: return "unknown";
+    }
+}
+
+static int32_t check_cfg(const dl_config* c) {
+    if (!c) return DL_ERR_BAD_ARG;
+    if (c->n_dims != 3 || c->hidden_nf != HID || c->inv_sublayers != 2 || c->condition_time != 1) return DL_ERR_UNSUPPORTED;
+    if (c->in_node_nf < 1 || 3 + c->in_node_nf > DMAX || c->in_node_nf > 16) return DL_ERR_UNSUPPORTED;
+    if (c->context_node_nf < 0 || c->context_node_nf > CTXMAX) return DL_ERR_UNSUPPORTED;
+    if (c->in_node_nf + 1 + c->context_node_nf > FINP) return DL_ERR_UNSUPPORTED;
+    if (c->n_layers < 1 || c->n_layers > 64) return DL_ERR_UNSUPPORTED;
+    if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
+    return DL_OK;
+}
+
+int32_t dl_model_num_tensors(const dl_config* cfg) {
+    if (!cfg) return DL_ERR_BAD_ARG;
+    return 4 + cfg->n_layers * (2 * 8 + 5);
+}
+
+int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_tensors, dl_model** out) {
+    int32_t st = check_cfg(cfg);
+    if (st != DL_OK) return st;
+    if (!w || !out || n_tensors != dl_model_num_tensors(cfg)) return DL_ERR_BAD_ARG;
+    for (int i = 0; i < n_tensors; ++i)
+        if (!w[i]) return DL_ERR_BAD_ARG;
+    const int nf = cfg->in_node_nf, fin = nf + 1 + cfg->context_node_nf, L = cfg->n_layers;
+    const size_t total = size_t(OFF_BLOCKS) + size_t(L) * BLOCK_SIZE;
+    float* hp = static_cast<float*>(calloc(total, sizeof(float)));
+    if (!hp) return DL_ERR_ALLOC;
+    const double c = -1.4426950408889634;            // -log2(e): y = c * pre-activation
+    const double inv_norm = 1.0 / double(cfg->normalization_factor);
+    int ti = 0;
+    // embedding [128][fin], bias; embedding_out [fin][128] (first nf rows kept), bias
+    const float* ew = w[ti++]; const float* eb = w[ti++];
+    const float* ow = w[ti++]; const float* ob = w[ti++];
+    for (int f = 0; f < HID; ++f) {
+        for (int k = 0; k < fin; ++k) hp[OFF_EMB_W + f * FINP + k] = ew[size_t(f) * fin + k];
+        hp[OFF_EMB_B + f] = eb[f];
+    }
+    for (int o = 0; o < nf; ++o) {
+        memcpy(hp + OFF_OUT_W + o * HID, ow + size_t(o) * HID, HID * sizeof(float));
+        hp[OFF_OUT_B + o] = ob[o];
+    }
+    for (int blk = 0; blk < L; ++blk) {
+        float* base = hp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
+        for (int gi = 0; gi < 2; ++gi) {
+            float* g = base + gi * GCL_SIZE;
+            const float* w1 = w[ti++]; const float* b1 = w[ti++];     // edge_mlp.0 [128][258]
+            const float* w2 = w[ti++]; const float* b2 = w[ti++];     // edge_mlp.2 [128][128]
+            const float* w3 = w[ti++]; const float* b3 = w[ti++];     // node_mlp.0 [128][256]
+            const float* w4 = w[ti++]; const float* b4 = w[ti++];     // node_mlp.2 [128][128]
+            const int ld1 = 2 * HID + 2;
+            pack_unit(g + G_W1A, w1, ld1, 0, c);
+            pack_unit(g + G_W1B, w1, ld1, HID, c);
+            pack_unit(g + G_W3A, w3, 2 * HID, 0, c);
+            pack_unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);         // agg arrives as c*norm*true agg
+            pack_unit(g + G_W4, w4, HID, 0, 1.0 / c);
+            pack_lds_image(g + G_W2, w2, HID, 1.0);
+            float* vv = g + G_VEC;
+            pack_vec(vv + 0 * HID, b1, 1, c);
+            pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);             // radial column
+            pack_vec(vv + 2 * HID, w1 + 2 * HID + 1, ld1, c);         // d0 column
+            pack_vec(vv + 3 * HID, b2, 1, c);
+            pack_vec(vv + 4 * HID, b3, 1, c);
+            pack_vec(vv + 5 * HID, b4, 1, 1.0);
+        }
+        float* e = base + 2 * GCL_SIZE;
+        const float* w5 = w[ti++]; const float* b5 = w[ti++];         // coord_mlp.0 [128][258]
+        const float* w6 = w[ti++]; const float* b6 = w[ti++];         // coord_mlp.2 [128][128]
+        const float* w7 = w[ti++];                                    // coord_mlp.4 [1][128], no bias
+        const int ld5 = 2 * HID + 2;
+        pack_unit(e + E_W5A, w5, ld5, 0, c);
+        pack_unit(e + E_W5B, w5, ld5, HID, c);
+        pack_lds_image(e + E_W6, w6, HID, 1.0);
+        float* vv = e + E_VEC;
+        pack_vec(vv + 0 * HID, b5, 1, c);
+        pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
+        pack_vec(vv + 2 * HID, w5 + 2 * HID + 1, ld5, c);
+        pack_vec(vv + 3 * HID, b6, 1, c);
+        pack_vec(vv + 4 * HID, w7, 1, inv_norm / c);
+    }
+    dl_model* m = static_cast<dl_model*>(calloc(1, sizeof(dl_model)));
+    if (!m) { free(hp); return DL_ERR_ALLOC; }
+    m->cfg = *cfg;
+    m->n_floats = total;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { free(hp); free(m); return DL_ERR_NO_DEVICE; }
+    if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&m->d_pack), total * sizeof(float))) ||
+        !hip_ok(hipMemcpy(m->d_pack, hp, total * sizeof(float), hipMemcpyHostToDevice))) {
+        free(hp); free(m); return DL_ERR_HIP;
+    }
+    free(hp);
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(egnn_forward_fc_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES))) ||
+            !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_chain_fc_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)))) {
+            hipFree(m->d_pack); free(m); return DL_ERR_HIP;
+        }
+        attr_done = true;
+    }
+    *out = m;
+    return DL_OK;
+}
+
+void dl_model_destroy(dl_model* m) {
+    if (!m) return;
+    if (m->d_pack) hipFree(m->d_pack);
+    free(m);
+}
+
+static ModelDims dims_of(const dl_model* m) {
+    ModelDims md;
+    md.nf = m->cfg.in_node_nf;
+    md.ctx = m->cfg.context_node_nf;
+    md.fin = md.nf + 1 + md.ctx;
+    md.n_layers = m->cfg.n_layers;
+    md.norm_constant = m->cfg.norm_constant;
+    return md;
+}
+
+int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
+                           int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
+                           const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
+                           void* stream) {
+    if (!m || !xh || !t || !node_mask || !out || !nan_flags || B < 0 || N < 1) return DL_ERR_BAD_ARG;
+    if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
+    if (B == 0) return DL_OK;
+    FwdArgs a;
+    a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
+    a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
+    a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags;
+    hipLaunchKernelGGL(egnn_forward_fc_kernel, dim3(B), dim3(THREADS), LDS_BYTES,
+                       static_cast<hipStream_t>(stream), a);
+    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+
+int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stream) {
+    if (!m || !g) return DL_ERR_BAD_ARG;
+    if (!g->x || !g->h || !g->node_mask || !g->fragment_mask || !g->linker_mask || !g->noise_x || !g->noise_h ||
+        !g->coefs || !g->chain || !g->nan_flags || !g->nan_step) return DL_ERR_BAD_ARG;
+    if (m->cfg.context_node_nf > 0 && !g->context) return DL_ERR_BAD_ARG;
+    if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T) return DL_ERR_BAD_ARG;
+    if (g->B == 0) return DL_OK;
+    ChainArgs a;
+    a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g;
+    hipLaunchKernelGGL(sample_chain_fc_kernel, dim3(g->B), dim3(THREADS), LDS_BYTES,
+                       static_cast<hipStream_t>(stream), a);
+    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+
+int32_t dl_sampler_step(int32_t B, int32_t N, int32_t D, const float* z_t, const float* eps_hat, const float* noise,
+                        const float* fragment_mask, const float* linker_mask, dl_step_coef coef, float* z_s,
+                        void* stream) {
+    if (!z_t || !eps_hat || !noise || !fragment_mask || !linker_mask || !z_s || B < 0 || N < 1 || D < 1)
+        return DL_ERR_BAD_ARG;
+    const int total = B * N * D;
+    if (total == 0) return DL_OK;
+    hipLaunchKernelGGL(sampler_step_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), total, D, z_t, eps_hat, noise, fragment_mask,
+                       linker_mask, coef, z_s);
+    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+
+}  // extern "C"

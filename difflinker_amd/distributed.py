@@ -1,0 +1,78 @@
+"""Multi-GPU sampling: molecules are independent (FC edges are intra-molecule, egnn.py:456-461;
+gamma scalars are per-step constants), so a sampling batch shards across ranks with no data-path
+collective; only the final frames are exchanged, by ONE all-gather (RCCL over xGMI when the
+process group's backend is ``nccl``; ``gloo`` in the CPU tests).
+
+One process per GPU (``torch.distributed``); rank r takes a contiguous slice of the collated
+batch.  Noise is drawn for the GLOBAL batch in the reference's call order and sliced, so the
+sample of molecule b does not depend on the world size.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous, balanced [lo, hi) slice of ``n_items`` for ``rank`` (first ``n_items % world``
+    ranks get one extra item)."""
+    base, extra = divmod(n_items, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sampler_inputs(inputs, rank, world_size):
+    """Slice the ``EDM.sample_chain`` tensors of a collated batch for one rank.
+
+    ``edge_mask`` is either the FC mask ``[B*N*N, 1]`` (sliced by molecule) or the pockets' batch-id
+    vector ``[B*N]`` (sliced and re-based so ids start at 0)."""
+    bs, n = inputs['x'].shape[0], inputs['x'].shape[1]
+    lo, hi = shard_bounds(bs, rank, world_size)
+    out = {}
+    for k, v in inputs.items():
+        if k == 'edge_mask' and v is not None:
+            if v.numel() == bs * n * n:
+                out[k] = v.view(bs, n * n)[lo:hi].reshape(-1, 1)
+            else:
+                out[k] = (v.view(bs, n)[lo:hi] - lo).reshape(-1)
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == bs:
+            out[k] = v[lo:hi]
+        else:
+            out[k] = v
+    return out, (lo, hi)
+
+
+def all_gather_frames(local_chain, batch_size, group=None):
+    """All-gather per-rank chains ``[K, B_r, N, D]`` into ``[K, B, N, D]`` (rank order = batch order).
+    Shards may differ by one molecule: they are padded to the largest shard for the collective."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local_chain
+    rank = dist.get_rank(group)
+    sizes = [shard_bounds(batch_size, r, world) for r in range(world)]
+    bmax = max(hi - lo for lo, hi in sizes)
+    k, b_r, n, d = local_chain.shape
+    assert b_r == sizes[rank][1] - sizes[rank][0]
+    send = local_chain.new_zeros((k, bmax, n, d))
+    send[:, :b_r] = local_chain
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send.contiguous(), group=group)
+    return torch.cat([recv[r][:, :sizes[r][1] - sizes[r][0]] for r in range(world)], dim=1)
+
+
+def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=None, gather=True):
+    """``edm.sample_chain`` on this rank's slice of the batch, then one all-gather of the frames.
+
+    ``inputs``: dict with the keyword tensors of ``EDM.sample_chain`` for the FULL batch (already on
+    this rank's device).  ``noise_bank``: optional global ``(noise_x, noise_h)``; when absent each rank
+    draws the global bank from its generator — seed all ranks identically for world-size-independent
+    samples."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    bs, n = inputs['x'].shape[0], inputs['x'].shape[1]
+    local, (lo, hi) = shard_sampler_inputs(inputs, rank, world)
+    if noise_bank is None and world > 1:
+        noise_bank = edm.draw_noise_bank(bs, n, inputs['x'].device)
+    kw = {}
+    if noise_bank is not None:
+        kw['noise_bank'] = (noise_bank[0][:, lo:hi].contiguous(), noise_bank[1][:, lo:hi].contiguous())
+    chain = edm.sample_chain(keep_frames=keep_frames, **local, **kw)
+    return all_gather_frames(chain, bs, group) if gather else chain

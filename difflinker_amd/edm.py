@@ -1,0 +1,303 @@
+"""``EDM`` — the ancestral sampler of DiffLinker, MI355X-native.
+
+Drop-in for the SAMPLING surface of reference ``src/edm.py::EDM`` (constructor edm.py:15-39,
+``sample_chain`` :126-176 and the helpers it uses).  With a fully-connected ``Dynamics`` the whole
+chain — T reverse steps (:178-208) + final decode (:210-242) — is ONE kernel launch
+(``dl_sample_chain_fc``): every molecule keeps its state in LDS of one compute unit for all T+1
+denoiser calls.  The noise is drawn up front with the reference's ``torch.randn`` call sequence
+(x-part then h-part, 2(T+2) calls on the tensors' device), so the same ``torch.manual_seed`` gives
+the same noise stream as the reference run on the same device.
+
+Out of scope (training only): ``EDM.forward`` and the likelihood/KL terms (edm.py:41-124, 244-326),
+``InpaintingEDM`` (edm.py:466-730), the learned ``GammaNetwork`` schedule.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib, utils
+from .egnn import Dynamics, DynamicsWithPockets
+from .noise import PredefinedNoiseSchedule
+
+
+class EDM(torch.nn.Module):
+    def __init__(
+            self,
+            dynamics,
+            in_node_nf: int,
+            n_dims: int,
+            timesteps: int = 1000,
+            noise_schedule='learned',
+            noise_precision=1e-4,
+            loss_type='vlb',
+            norm_values=(1., 1., 1.),
+            norm_biases=(None, 0., 0.),
+    ):
+        super().__init__()
+        if noise_schedule == 'learned':
+            raise NotImplementedError("noise_schedule='learned' (GammaNetwork) is training-only and out of scope; "
+                                      'released configs use polynomial_2')
+        self.gamma = PredefinedNoiseSchedule(noise_schedule, timesteps=timesteps, precision=noise_precision)
+        self.dynamics = dynamics
+        self.in_node_nf = in_node_nf
+        self.n_dims = n_dims
+        self.T = timesteps                      # callers overwrite it for --n_steps (generate.py:103-104)
+        self.norm_values = norm_values
+        self.norm_biases = norm_biases
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('EDM.forward is the training loss (edm.py:41-124): out of scope of the '
+                                  'sampling hot path')
+
+    # ---- gamma algebra (host scalars; edm.py:369-403) -----------------------------------------------
+    def sigma(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(gamma)), target_tensor)
+
+    def alpha(self, gamma, target_tensor):
+        return self.inflate_batch_array(torch.sqrt(torch.sigmoid(-gamma)), target_tensor)
+
+    def SNR(self, gamma):
+        return torch.exp(-gamma)
+
+    def sigma_and_alpha_t_given_s(self, gamma_t, gamma_s, target_tensor):
+        sigma2_t_given_s = self.inflate_batch_array(
+            -torch.expm1(F.softplus(gamma_s) - F.softplus(gamma_t)), target_tensor)
+        log_alpha2_t_given_s = F.logsigmoid(-gamma_t) - F.logsigmoid(-gamma_s)
+        alpha_t_given_s = self.inflate_batch_array(torch.exp(0.5 * log_alpha2_t_given_s), target_tensor)
+        return sigma2_t_given_s, torch.sqrt(sigma2_t_given_s), alpha_t_given_s
+
+    @staticmethod
+    def inflate_batch_array(array, target):
+        return array.view((array.size(0),) + (1,) * (len(target.size()) - 1))
+
+    @staticmethod
+    def numbers_of_nodes(mask):
+        return torch.sum(mask.squeeze(2), dim=1)
+
+    # ---- (un)normalisation (edm.py:347-361) ---------------------------------------------------------
+    def normalize(self, x, h):
+        return x / self.norm_values[0], (h.float() - self.norm_biases[1]) / self.norm_values[1]
+
+    def unnormalize(self, x, h):
+        return x * self.norm_values[0], h * self.norm_values[1] + self.norm_biases[1]
+
+    def unnormalize_z(self, z):
+        assert z.size(2) == self.n_dims + self.in_node_nf
+        x, h = self.unnormalize(z[:, :, :self.n_dims], z[:, :, self.n_dims:])
+        return torch.cat([x, h], dim=2)
+
+    # ---- noise (edm.py:328-345) ---------------------------------------------------------------------
+    def sample_combined_position_feature_noise(self, n_samples, n_nodes, mask):
+        z_x = utils.sample_gaussian_with_mask(size=(n_samples, n_nodes, self.n_dims), device=mask.device,
+                                              node_mask=mask)
+        z_h = utils.sample_gaussian_with_mask(size=(n_samples, n_nodes, self.in_node_nf), device=mask.device,
+                                              node_mask=mask)
+        return torch.cat([z_x, z_h], dim=2)
+
+    def sample_normal(self, mu, sigma, node_mask):
+        return mu + sigma * self.sample_combined_position_feature_noise(mu.size(0), mu.size(1), node_mask)
+
+    def draw_noise_bank(self, n_samples, n_nodes, device, n_steps=None):
+        """All 2(T+2) standard-normal draws of one chain, in the reference's call order and shapes
+        (x-part ``[B,N,3]`` then h-part ``[B,N,nf]``; initial z, T steps, decode), unmasked — the kernels
+        apply ``linker_mask``.  Returns (noise_x [T+2,B,N,3], noise_h [T+2,B,N,nf])."""
+        n_steps = self.T if n_steps is None else n_steps
+        noise_x = torch.empty((n_steps + 2, n_samples, n_nodes, self.n_dims), device=device)
+        noise_h = torch.empty((n_steps + 2, n_samples, n_nodes, self.in_node_nf), device=device)
+        for k in range(n_steps + 2):
+            noise_x[k] = torch.randn((n_samples, n_nodes, self.n_dims), device=device)
+            noise_h[k] = torch.randn((n_samples, n_nodes, self.in_node_nf), device=device)
+        return noise_x, noise_h
+
+    # ---- per-step scalars ---------------------------------------------------------------------------
+    def step_coefficients(self, batch_size=1):
+        """Host (CPU fp32) restatement of the scalar algebra of every reverse step, in execution order
+        s = T-1 ... 0 (edm.py:147-150,180-185,199,202) and of the final decode (:213-216,237-242).
+
+        Evaluated per step on ``[batch_size, 1]`` tensors exactly as the reference does: PyTorch's CPU
+        transcendentals round differently on its vectorised and scalar paths, and the cancellation in
+        sigma^2_{t|s} amplifies that to ~2e-5, so the shape is part of the parity contract.
+        Returns (coefs [T,4] = (t, alpha_ts, c_eps, sigma), (inv_alpha0, sigma0, sigma_x))."""
+        key = (self.T, int(batch_size))
+        cached = getattr(self, '_coef_cache', None)
+        if cached is not None and cached[0] == key and cached[1] == self.gamma.gamma._version:
+            return cached[2]
+        gamma = self.gamma.gamma.detach().to('cpu', torch.float32)
+        timesteps = self.gamma.timesteps
+        lookup = lambda tt: gamma[torch.round(tt * timesteps).long()]
+        rows = []
+        for s_int in reversed(range(0, self.T)):
+            s = torch.full((batch_size, 1), fill_value=s_int)
+            t = (s + 1) / self.T
+            s = s / self.T
+            gamma_s, gamma_t = lookup(s), lookup(t)
+            sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, gamma_t)
+            sigma_s = torch.sqrt(torch.sigmoid(gamma_s))
+            sigma_t = torch.sqrt(torch.sigmoid(gamma_t))
+            c_eps = sigma2_ts / alpha_ts / sigma_t
+            sigma = sigma_ts * sigma_s / sigma_t
+            rows.append(torch.stack([t[0, 0], alpha_ts[0, 0], c_eps[0, 0], sigma[0, 0]]))
+        coefs = torch.stack(rows).to(torch.float32).contiguous()
+        gamma_0 = lookup(torch.zeros(batch_size, 1))
+        sigma_x = self.SNR(-0.5 * gamma_0)[0, 0]
+        inv_alpha0 = (1. / torch.sqrt(torch.sigmoid(-gamma_0)))[0, 0]
+        sigma0 = torch.sqrt(torch.sigmoid(gamma_0))[0, 0]
+        out = (coefs, (float(inv_alpha0), float(sigma0), float(sigma_x)))
+        self._coef_cache = (key, self.gamma.gamma._version, out)
+        return out
+
+    # ---- one reverse step / decode, host-driven (edm.py:178-242) --------------------------------------
+    def sample_p_zs_given_zt_only_linker(self, s, t, z_t, node_mask, fragment_mask, linker_mask, edge_mask, context):
+        """Samples z_s ~ p(z_s | z_t) for the linker atoms (edm.py:178-208): HIP denoiser + fused HIP tail."""
+        gamma_s, gamma_t = self.gamma(s), self.gamma(t)
+        sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, z_t)
+        sigma_s, sigma_t = self.sigma(gamma_s, target_tensor=z_t), self.sigma(gamma_t, target_tensor=z_t)
+        eps_hat = self.dynamics.forward(xh=z_t, t=t, node_mask=node_mask, linker_mask=linker_mask,
+                                        context=context, edge_mask=edge_mask)
+        c_eps = sigma2_ts / alpha_ts / sigma_t
+        sigma = sigma_ts * sigma_s / sigma_t
+        bs, n, d = z_t.shape
+        noise = torch.cat([torch.randn((bs, n, self.n_dims), device=z_t.device),
+                           torch.randn((bs, n, self.in_node_nf), device=z_t.device)], dim=2)
+        # the reference broadcasts per-sample scalars that are identical across the batch (edm.py:147-150)
+        coef = _lib.DLStepCoef(float(t.reshape(-1)[0]), float(alpha_ts.reshape(-1)[0]), float(c_eps.reshape(-1)[0]),
+                               float(sigma.reshape(-1)[0]))
+        return self._sampler_step(z_t, eps_hat, noise, fragment_mask, linker_mask, coef)
+
+    def _sampler_step(self, z_t, eps_hat, noise, fragment_mask, linker_mask, coef):
+        lib = _lib.load()
+        if z_t.device.type != 'cuda':
+            raise RuntimeError('difflinker_amd.EDM runs on the GPU only (no CPU fallback)')
+        bs, n, d = z_t.shape
+        z_t, eps_hat, noise = z_t.float().contiguous(), eps_hat.float().contiguous(), noise.float().contiguous()
+        fm = fragment_mask.reshape(bs, n).float().contiguous()
+        lm = linker_mask.reshape(bs, n).float().contiguous()
+        z_s = torch.empty_like(z_t)
+        with torch.cuda.device(z_t.device):
+            stream = torch.cuda.current_stream(z_t.device).cuda_stream
+            _lib.check(lib.dl_sampler_step(bs, n, d, _lib.ptr(z_t), _lib.ptr(eps_hat), _lib.ptr(noise), _lib.ptr(fm),
+                                           _lib.ptr(lm), coef, _lib.ptr(z_s), ctypes.c_void_p(stream)),
+                       'dl_sampler_step')
+        return z_s
+
+    def compute_x_pred(self, eps_t, z_t, gamma_t):
+        sigma_t = self.sigma(gamma_t, target_tensor=eps_t)
+        alpha_t = self.alpha(gamma_t, target_tensor=eps_t)
+        return 1. / alpha_t * (z_t - sigma_t * eps_t)
+
+    def sample_p_xh_given_z0_only_linker(self, z_0, node_mask, fragment_mask, linker_mask, edge_mask, context):
+        """Samples x,h ~ p(x,h | z_0) for the linker atoms (edm.py:210-235), host-driven."""
+        zeros = torch.zeros(size=(z_0.size(0), 1), device=z_0.device)
+        gamma_0 = self.gamma(zeros)
+        sigma_x = self.SNR(-0.5 * gamma_0).unsqueeze(1)
+        eps_hat = self.dynamics.forward(t=zeros, xh=z_0, node_mask=node_mask, linker_mask=linker_mask,
+                                        edge_mask=edge_mask, context=context)
+        eps_hat = eps_hat * linker_mask
+        mu_x = self.compute_x_pred(eps_t=eps_hat, z_t=z_0, gamma_t=gamma_0)
+        xh = self.sample_normal(mu=mu_x, sigma=sigma_x, node_mask=linker_mask)
+        xh = z_0 * fragment_mask + xh * linker_mask
+        x, h = self.unnormalize(xh[:, :, :self.n_dims], xh[:, :, self.n_dims:])
+        h = F.one_hot(torch.argmax(h, dim=2), self.in_node_nf) * node_mask
+        return x, h
+
+    # ---- the chain ------------------------------------------------------------------------------------
+    def _fused_ok(self):
+        return isinstance(self.dynamics, Dynamics) and not isinstance(self.dynamics, DynamicsWithPockets) \
+            and self.dynamics.graph_type == 'FC' and not self.dynamics.centering
+
+    @torch.no_grad()
+    def sample_chain(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames=None,
+                     noise_bank=None):
+        """``EDM.sample_chain`` (edm.py:126-176).  Returns ``chain [keep_frames, B, N, 3+nf]`` whose frame 0
+        is the final sample ``[x, one_hot(h)]``.
+
+        ``noise_bank`` (optional, not in the reference signature) = ``(noise_x [T+2,B,N,3], noise_h
+        [T+2,B,N,nf])`` replaces the internal ``torch.randn`` draws (parity tests share one bank with the
+        CPU oracle).
+        """
+        if keep_frames is None:
+            keep_frames = self.T
+        else:
+            assert keep_frames <= self.T
+        if not self._fused_ok():
+            return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
+                                                keep_frames)
+        dev = x.device
+        if dev.type != 'cuda':
+            raise RuntimeError('difflinker_amd.EDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
+        lib = _lib.load()
+        bs, n = x.size(0), x.size(1)
+        nf, T = self.in_node_nf, self.T
+        handle = self.dynamics.hip_model(dev)
+        if noise_bank is None:
+            noise_x, noise_h = self.draw_noise_bank(bs, n, dev)
+        else:
+            noise_x, noise_h = (t.to(dev, torch.float32).contiguous() for t in noise_bank)
+            assert tuple(noise_x.shape) == (T + 2, bs, n, self.n_dims) and tuple(noise_h.shape) == (T + 2, bs, n, nf)
+        coefs, (inv_alpha0, sigma0, sigma_x) = self.step_coefficients(bs)
+        coefs = coefs.to(dev)
+        f32 = lambda t_, shape: t_.reshape(shape).to(torch.float32).contiguous()
+        xs, hs = f32(x, (bs, n, self.n_dims)), f32(h, (bs, n, nf))
+        nm = node_mask.reshape(bs, n).to(torch.int8).contiguous()
+        fm, lm = f32(fragment_mask, (bs, n)), f32(linker_mask, (bs, n))
+        em = edge_mask.reshape(bs, n, n).to(torch.int8).contiguous() if edge_mask is not None else None
+        ctx = f32(context, (bs, n, self.dynamics.context_node_nf)) if context is not None else None
+        chain = torch.zeros((keep_frames, bs, n, self.n_dims + nf), device=dev)
+        flags = torch.zeros(bs, dtype=torch.int32, device=dev)
+        steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+        args = _lib.DLChainArgs(
+            B=bs, N=n, T=T, keep_frames=keep_frames,
+            x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
+            linker_mask=lm.data_ptr(), edge_mask=em.data_ptr() if em is not None else None,
+            context=ctx.data_ptr() if ctx is not None else None,
+            noise_x=noise_x.data_ptr(), noise_h=noise_h.data_ptr(), coefs=coefs.data_ptr(),
+            inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
+            norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
+            chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr())
+        with torch.cuda.device(dev):
+            cur = torch.cuda.current_stream(dev)
+            if getattr(self, 'profile_events', False):     # bench.py: HIP events right around the launch
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(cur)
+            _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args), ctypes.c_void_p(cur.cuda_stream)),
+                       'dl_sample_chain_fc')
+            if getattr(self, 'profile_events', False):
+                ev1.record(cur)
+                self.last_kernel_events = (ev0, ev1)
+        self._raise_on_chain_flags(flags, steps)
+        return chain
+
+    def _raise_on_chain_flags(self, flags, steps):
+        """The reference raises at the first denoiser call whose output holds a NaN (egnn.py:441-442);
+        the fused chain reports, per molecule, its first offending call — raise for the earliest one."""
+        if bool(flags.any()):
+            f, st = flags.cpu(), steps.cpu()
+            if bool((f & 4).any()):
+                raise ValueError(f'molecule with more than {_lib.load().dl_max_atoms()} real atoms: '
+                                 'outside the LDS-resident fully-connected kernel')
+            first = int(st[f != 0].min())
+            raise utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
+
+    def _sample_chain_host_loop(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames):
+        """Reference-shaped loop for dynamics the fused kernel does not cover: one HIP denoiser launch and
+        one fused HIP tail per step (edm.py:126-176)."""
+        n_samples, n_nodes = x.size(0), x.size(1)
+        x, h = self.normalize(x, h)
+        xh = torch.cat([x, h], dim=2)
+        z = self.sample_combined_position_feature_noise(n_samples, n_nodes, mask=linker_mask)
+        z = xh * fragment_mask + z * linker_mask
+        chain = torch.zeros((keep_frames,) + z.size(), device=z.device)
+        for s in reversed(range(0, self.T)):
+            s_array = torch.full((n_samples, 1), fill_value=s, device=z.device)
+            t_array = (s_array + 1) / self.T
+            s_array = s_array / self.T
+            z = self.sample_p_zs_given_zt_only_linker(s=s_array, t=t_array, z_t=z, node_mask=node_mask,
+                                                      fragment_mask=fragment_mask, linker_mask=linker_mask,
+                                                      edge_mask=edge_mask, context=context)
+            chain[(s * keep_frames) // self.T] = self.unnormalize_z(z)
+        x, h = self.sample_p_xh_given_z0_only_linker(z_0=z, node_mask=node_mask, fragment_mask=fragment_mask,
+                                                     linker_mask=linker_mask, edge_mask=edge_mask, context=context)
+        chain[0] = torch.cat([x, h], dim=2)
+        return chain

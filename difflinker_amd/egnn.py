@@ -1,0 +1,294 @@
+"""``Dynamics`` / ``DynamicsWithPockets`` — the denoiser boundary of DiffLinker, MI355X-native.
+
+Drop-in for reference ``src/egnn.py::Dynamics`` (constructor egnn.py:324-329, ``forward`` :374-447):
+same constructor signature, same attribute names, same ``state_dict`` keys
+(``dynamics.embedding.weight`` ... ``dynamics.e_block_{i}.gcl_{j}.edge_mlp.{0,2}.{weight,bias}`` ...,
+``dynamics.e_block_{i}.gcl_equiv.coord_mlp.{0,2,4}``), so a reference checkpoint loads unchanged.
+
+The modules below only OWN the parameters (in the reference's registration order, so the same
+``torch.manual_seed`` gives the same initial weights); all arithmetic of ``forward`` runs in the
+hand-written HIP kernels of ``csrc/egnn_fc.hip`` through the C ABI (``include/difflinker_hip.h``).
+There is no PyTorch/CPU fallback: CPU tensors, a missing HIP library or hyper-parameters outside
+the HIP path raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, utils
+
+
+class _ParamOnly(nn.Module):
+    """Parameter container: its arithmetic lives in the HIP kernels."""
+
+    def forward(self, *args, **kwargs):  # pragma: no cover
+        raise RuntimeError(f'{type(self).__name__} holds parameters only; call Dynamics.forward '
+                           '(HIP path, no PyTorch fallback)')
+
+
+def _mlp(sizes, activation, last_activation):
+    layers = []
+    for k in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[k], sizes[k + 1]))
+        if k < len(sizes) - 2 or last_activation:
+            layers.append(activation)
+    return nn.Sequential(*layers)
+
+
+class GCL(_ParamOnly):
+    """Edge MLP (2*nf+edges_in_d -> hidden -> hidden, activation after both) and node MLP
+    (hidden+nf -> hidden -> nf).  Parameters of reference ``GCL`` (egnn.py:10-43)."""
+
+    def __init__(self, input_nf, output_nf, hidden_nf, normalization_factor, aggregation_method, activation,
+                 edges_in_d=0):
+        super().__init__()
+        self.normalization_factor = normalization_factor
+        self.aggregation_method = aggregation_method
+        self.edge_mlp = _mlp([2 * input_nf + edges_in_d, hidden_nf, hidden_nf], activation, last_activation=True)
+        self.node_mlp = _mlp([hidden_nf + input_nf, hidden_nf, output_nf], activation, last_activation=False)
+
+
+class EquivariantUpdate(_ParamOnly):
+    """Coordinate MLP (2*hidden+edges_in_d -> hidden -> hidden -> 1, last layer bias-free with
+    xavier gain 0.001).  Parameters of reference ``EquivariantUpdate`` (egnn.py:83-99)."""
+
+    def __init__(self, hidden_nf, normalization_factor, aggregation_method, edges_in_d=1, activation=nn.SiLU()):
+        super().__init__()
+        head = nn.Linear(hidden_nf, 1, bias=False)                 # created first, like the reference
+        torch.nn.init.xavier_uniform_(head.weight, gain=0.001)
+        body = _mlp([2 * hidden_nf + edges_in_d, hidden_nf, hidden_nf], activation, last_activation=True)
+        self.coord_mlp = nn.Sequential(*body, head)
+        self.normalization_factor = normalization_factor
+        self.aggregation_method = aggregation_method
+
+
+class EquivariantBlock(_ParamOnly):
+    """``inv_sublayers`` GCLs + one EquivariantUpdate (egnn.py:128-155)."""
+
+    def __init__(self, hidden_nf, edge_feat_nf, activation, n_layers, norm_constant, normalization_factor,
+                 aggregation_method):
+        super().__init__()
+        self.hidden_nf = hidden_nf
+        self.n_layers = n_layers
+        self.norm_constant = norm_constant
+        for i in range(n_layers):
+            self.add_module(f'gcl_{i}', GCL(hidden_nf, hidden_nf, hidden_nf, normalization_factor,
+                                            aggregation_method, activation, edges_in_d=edge_feat_nf))
+        self.add_module('gcl_equiv', EquivariantUpdate(hidden_nf, normalization_factor, aggregation_method,
+                                                       edges_in_d=edge_feat_nf, activation=activation))
+
+
+class EGNN(_ParamOnly):
+    """Embedding, ``n_layers`` EquivariantBlocks, output projection (egnn.py:181-216)."""
+
+    def __init__(self, in_node_nf, hidden_nf, activation, n_layers, norm_constant, inv_sublayers,
+                 normalization_factor, aggregation_method, out_node_nf=None):
+        super().__init__()
+        out_node_nf = in_node_nf if out_node_nf is None else out_node_nf
+        self.hidden_nf = hidden_nf
+        self.n_layers = n_layers
+        self.normalization_factor = normalization_factor
+        self.aggregation_method = aggregation_method
+        self.embedding = nn.Linear(in_node_nf, hidden_nf)
+        self.embedding_out = nn.Linear(hidden_nf, out_node_nf)
+        for i in range(n_layers):
+            self.add_module(f'e_block_{i}', EquivariantBlock(
+                hidden_nf, edge_feat_nf=2, activation=activation, n_layers=inv_sublayers,
+                norm_constant=norm_constant, normalization_factor=normalization_factor,
+                aggregation_method=aggregation_method))
+
+
+def egnn_tensor_order(n_layers, inv_sublayers=2):
+    """state_dict keys of the EGNN in the order ``dl_model_create`` expects (include/difflinker_hip.h)."""
+    keys = ['embedding.weight', 'embedding.bias', 'embedding_out.weight', 'embedding_out.bias']
+    for i in range(n_layers):
+        for j in range(inv_sublayers):
+            for mlp in ('edge_mlp', 'node_mlp'):
+                for k in (0, 2):
+                    keys += [f'e_block_{i}.gcl_{j}.{mlp}.{k}.weight', f'e_block_{i}.gcl_{j}.{mlp}.{k}.bias']
+        for k in (0, 2):
+            keys += [f'e_block_{i}.gcl_equiv.coord_mlp.{k}.weight', f'e_block_{i}.gcl_equiv.coord_mlp.{k}.bias']
+        keys.append(f'e_block_{i}.gcl_equiv.coord_mlp.4.weight')
+    return keys
+
+
+class _HipModel:
+    """Owner of one ``dl_model`` handle (packed weights in HBM of one device)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().dl_model_destroy(self.handle)
+        except Exception:  # pragma: no cover  (interpreter shutdown)
+            pass
+        self.handle = None
+
+
+class Dynamics(nn.Module):
+    """EGNN denoiser on the fully-connected molecular graph.  Reference: ``Dynamics`` egnn.py:323-467."""
+
+    def __init__(
+            self, n_dims, in_node_nf, context_node_nf, hidden_nf=64, device='cpu', activation=nn.SiLU(),
+            n_layers=4, attention=False, condition_time=True, tanh=False, norm_constant=0, inv_sublayers=2,
+            sin_embedding=False, normalization_factor=100, aggregation_method='sum', model='egnn_dynamics',
+            normalization=None, centering=False, graph_type='FC',
+    ):
+        super().__init__()
+        if model != 'egnn_dynamics':
+            # reference: 'gnn_dynamics' builds a plain GNN, anything else NotImplementedError (egnn.py:355-370)
+            raise NotImplementedError(f"model={model!r}: the HIP path implements 'egnn_dynamics' only")
+        unsupported = []
+        if attention: unsupported.append('attention=True')
+        if tanh: unsupported.append('tanh=True')
+        if sin_embedding: unsupported.append('sin_embedding=True')
+        if aggregation_method != 'sum': unsupported.append(f'aggregation_method={aggregation_method!r}')
+        if not isinstance(activation, nn.SiLU): unsupported.append(f'activation={activation!r}')
+        if hidden_nf != 128: unsupported.append(f'hidden_nf={hidden_nf}')
+        if inv_sublayers != 2: unsupported.append(f'inv_sublayers={inv_sublayers}')
+        if not condition_time: unsupported.append('condition_time=False')
+        if n_dims != 3: unsupported.append(f'n_dims={n_dims}')
+        if unsupported:
+            raise NotImplementedError('hyper-parameters outside the HIP path (released configs use none of them): '
+                                      + ', '.join(unsupported))
+        self.device = device
+        self.n_dims = n_dims
+        self.in_node_nf = in_node_nf                   # atom-type channels (before time/context are appended)
+        self.context_node_nf = context_node_nf
+        self.condition_time = condition_time
+        self.model = model
+        self.centering = centering
+        self.graph_type = graph_type
+        self.norm_constant = norm_constant
+        self.normalization_factor = normalization_factor
+        # `normalization` (batch_norm in the YAMLs) is only forwarded to the GNN branch by the reference
+        # (egnn.py:341-368): a no-op for egnn_dynamics, accepted and ignored here too.
+        self.dynamics = EGNN(
+            in_node_nf=in_node_nf + context_node_nf + int(condition_time), hidden_nf=hidden_nf,
+            activation=activation, n_layers=n_layers, norm_constant=norm_constant, inv_sublayers=inv_sublayers,
+            normalization_factor=normalization_factor, aggregation_method=aggregation_method)
+        self.n_layers = n_layers
+        self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
+        self._hip_models = {}                          # device index -> (_HipModel, weight version)
+
+    # ---- packed weights -----------------------------------------------------------------------------
+    def _weight_version(self):
+        return tuple(p._version for p in self.dynamics.parameters()) + \
+            tuple(p.data_ptr() for p in self.dynamics.parameters())
+
+    def invalidate_packed(self):
+        self._hip_models.clear()
+
+    def _apply(self, fn, *args, **kwargs):
+        self._hip_models.clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    def hip_config(self):
+        return _lib.DLConfig(n_dims=self.n_dims, in_node_nf=self.in_node_nf, context_node_nf=self.context_node_nf,
+                             hidden_nf=self.dynamics.hidden_nf, n_layers=self.n_layers, inv_sublayers=2,
+                             condition_time=1, norm_constant=float(self.norm_constant),
+                             normalization_factor=float(self.normalization_factor))
+
+    def hip_model(self, device):
+        """``dl_model`` handle for ``device`` (packs + uploads the weights on first use / after a change)."""
+        if device.type != 'cuda':
+            raise RuntimeError('difflinker_amd.Dynamics runs on the GPU only (HIP kernels, no CPU fallback); '
+                               f'got tensors on {device}')
+        lib = _lib.load()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        version = self._weight_version()
+        cached = self._hip_models.get(index)
+        if cached is not None and cached[1] == version:
+            return cached[0].handle
+        sd = self.dynamics.state_dict()
+        host = [sd[k].detach().to('cpu', torch.float32).contiguous() for k in egnn_tensor_order(self.n_layers)]
+        cfg = self.hip_config()
+        assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == len(host)
+        arr = (ctypes.c_void_p * len(host))(*[t.data_ptr() for t in host])
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(index):
+            _lib.check(lib.dl_model_create(ctypes.byref(cfg), arr, len(host), ctypes.byref(handle)),
+                       'dl_model_create')
+        self._hip_models[index] = (_HipModel(handle), version)
+        return handle
+
+    # ---- forward ------------------------------------------------------------------------------------
+    @staticmethod
+    def _f32(t):
+        return None if t is None else t.to(torch.float32).contiguous()
+
+    def _launch_forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+        lib = _lib.load()
+        dev = xh.device
+        bs, n_nodes = xh.shape[0], xh.shape[1]
+        handle = self.hip_model(dev)
+        xh = self._f32(xh)
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)])
+        t = t.to(dev, torch.float32).contiguous().view(-1)
+        t_is_scalar = int(t.numel() == 1)                       # egnn.py:397-399
+        assert t_is_scalar or t.numel() == bs
+        nm = node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous()
+        lm = self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None
+        em = edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None
+        ctx = self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None
+        out = torch.empty_like(xh)
+        flags = torch.empty(bs, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.dl_egnn_forward_fc(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
+                                              _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
+                                              _lib.ptr(out), _lib.ptr(flags), ctypes.c_void_p(stream)),
+                       'dl_egnn_forward_fc')
+        return out, flags
+
+    def _raise_on_flags(self, flags):
+        """One D2H sync per forward, like the reference's ``torch.any(torch.isnan(..))`` (egnn.py:441-442)."""
+        if bool(flags.any()):
+            f = flags.cpu()
+            if bool((f & 4).any()):
+                raise ValueError(f'molecule with more than {_lib.load().dl_max_atoms()} real atoms: '
+                                 'outside the LDS-resident fully-connected kernel')
+            raise utils.FoundNaNException.from_flags(f)
+
+    def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+        """
+        - t: (B, 1) or a single value     - xh: (B, N, 3 + nf)       - node_mask: (B, N, 1)
+        - linker_mask: (B, N, 1) or None  - edge_mask: (B*N*N, 1) int8 {0,-1,-2}   - context: (B, N, C)
+        Returns eps_hat (B, N, 3 + nf) = cat[vel, h_final]; raises ``utils.FoundNaNException``.
+        """
+        assert self.graph_type == 'FC'
+        out, flags = self._launch_forward(t, xh, node_mask, linker_mask, edge_mask, context)
+        self._raise_on_flags(flags)
+        if self.centering:                                     # inpainting only (egnn.py:444-445)
+            nm = node_mask.reshape(xh.shape[0], xh.shape[1], 1).to(out.dtype)
+            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], nm)
+            out = torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
+        return out
+
+    def get_edges(self, n_nodes, batch_size):
+        """Fully-connected edge list ``e = b*N*N + i*N + j`` (egnn.py:449-467).  Not used by the
+        kernels (pairs are enumerated by index arithmetic on chip); kept for API parity."""
+        cache = self.edge_cache.setdefault(n_nodes, {})
+        if batch_size not in cache:
+            e = torch.arange(batch_size * n_nodes * n_nodes)
+            b, i, j = e // (n_nodes * n_nodes), (e // n_nodes) % n_nodes, e % n_nodes
+            cache[batch_size] = [(b * n_nodes + i).to(self.device), (b * n_nodes + j).to(self.device)]
+        return cache[batch_size]
+
+
+class DynamicsWithPockets(Dynamics):
+    """Pocket-conditioned denoiser on the radius graph (reference egnn.py:470-596).
+
+    Row a13 of SURVEY.md section 8 — the sparse-edge HIP kernel is the next scope row; until it lands
+    this class loads checkpoints (same parameters) and fails loudly on ``forward``.
+    """
+
+    def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+        assert self.graph_type in ['4A', 'FC-4A', 'FC-10A-4A']
+        raise NotImplementedError('DynamicsWithPockets.forward: radius-graph HIP kernel not built yet '
+                                  '(no PyTorch fallback by design)')

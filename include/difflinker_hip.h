@@ -1,0 +1,148 @@
+/*
+ * difflinker_hip.h — C ABI of the MI355X (gfx950) implementation of DiffLinker's EGNN
+ * denoising-diffusion sampling hot path.
+ *
+ * The reference (igashov/DiffLinker) is pure Python/PyTorch and has no FFI of its own; the
+ * entry points below are what a native replacement of its hot path binds, one per reference
+ * interface (file:line into the reference tree):
+ *
+ *   dl_model_create / dl_model_destroy   <- Dynamics.__init__ + load_state_dict
+ *                                           src/egnn.py:324-372, src/lightning.py:81-100
+ *   dl_egnn_forward_fc                   <- Dynamics.forward (FC graph)       src/egnn.py:374-447
+ *                                           (EGNN.forward :218-238, EquivariantBlock :157-178,
+ *                                            GCL :45-80, EquivariantUpdate :101-125,
+ *                                            coord2diff :295-301, unsorted_segment_sum :304-320)
+ *   dl_sampler_step                      <- EDM.sample_p_zs_given_zt_only_linker, the part after
+ *                                           the denoiser call                   src/edm.py:198-208
+ *   dl_sample_chain_fc                   <- EDM.sample_chain                  src/edm.py:126-176
+ *                                           (+ :178-208 reverse step, :210-242 final decode,
+ *                                            :328-361 noise / (un)normalisation)
+ *
+ * Conventions
+ *   - every pointer marked "device" is a HIP device pointer owned by the caller (PyTorch-ROCm
+ *     tensors' data_ptr()); the library allocates nothing per call; `stream` is a hipStream_t
+ *     passed as void* (0 = default stream); calls are asynchronous on that stream.
+ *   - all floating point is fp32; masks are int8 (node_mask, edge_mask) or fp32 (fragment /
+ *     linker masks, context) exactly as the reference's collate produces them.
+ *   - return value: 0 on success, a negative dl_status otherwise; dl_error_string() names it.
+ *     There is NO CPU fallback: on a machine without a gfx950 device the compute entry points
+ *     return DL_ERR_NO_DEVICE / a HIP error.
+ */
+#ifndef DIFFLINKER_HIP_H
+#define DIFFLINKER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL_ABI_VERSION 1
+
+typedef enum dl_status {
+    DL_OK = 0,
+    DL_ERR_BAD_ARG = -1,        /* null pointer / inconsistent sizes                       */
+    DL_ERR_UNSUPPORTED = -2,    /* hyper-parameter outside the HIP path (see dl_config)    */
+    DL_ERR_TOO_MANY_ATOMS = -3, /* a molecule has more real atoms than dl_max_atoms()      */
+    DL_ERR_HIP = -4,            /* a HIP runtime call failed (see dl_last_hip_error())     */
+    DL_ERR_NO_DEVICE = -5,      /* no gfx950 device visible                                */
+    DL_ERR_ALLOC = -6
+} dl_status;
+
+/* Dynamics.__init__ hyper-parameters (src/egnn.py:324-329).  The HIP path implements the
+ * released-config surface: model='egnn_dynamics', SiLU, attention=False, tanh=False,
+ * sin_embedding=False, aggregation_method='sum', hidden_nf=128, inv_sublayers=2. */
+typedef struct dl_config {
+    int32_t n_dims;               /* 3                                              */
+    int32_t in_node_nf;           /* atom-type channels nf (8 ZINC, 9 GEOM/pockets) */
+    int32_t context_node_nf;      /* 1..4                                           */
+    int32_t hidden_nf;            /* must be 128                                    */
+    int32_t n_layers;             /* EquivariantBlocks (6 GEOM, 8 ZINC)             */
+    int32_t inv_sublayers;        /* must be 2                                      */
+    int32_t condition_time;       /* must be 1                                      */
+    float norm_constant;          /* 1e-6 in the released configs                   */
+    float normalization_factor;   /* 100                                            */
+} dl_config;
+
+typedef struct dl_model dl_model; /* opaque: packed, pre-scaled weights resident in HBM */
+
+/* Number of weight tensors dl_model_create expects: 4 + n_layers * (2*8 + 5). */
+int32_t dl_model_num_tensors(const dl_config* cfg);
+
+/* Pack the reference's nn.Linear tensors ([out,in] row-major fp32, HOST pointers) into the
+ * kernel layout and upload them.  `weights` lists the tensors in the reference state_dict
+ * order of the `Dynamics.dynamics` (EGNN) module:
+ *   embedding.weight, embedding.bias, embedding_out.weight, embedding_out.bias, then per block i:
+ *   gcl_0.edge_mlp.0.{weight,bias}, gcl_0.edge_mlp.2.{weight,bias}, gcl_0.node_mlp.0.{weight,bias},
+ *   gcl_0.node_mlp.2.{weight,bias}, (same for gcl_1),
+ *   gcl_equiv.coord_mlp.0.{weight,bias}, gcl_equiv.coord_mlp.2.{weight,bias}, gcl_equiv.coord_mlp.4.weight */
+int32_t dl_model_create(const dl_config* cfg, const float* const* weights, int32_t n_tensors, dl_model** out);
+void dl_model_destroy(dl_model* m);
+
+/* Largest number of REAL atoms per molecule the LDS-resident fully-connected kernel takes. */
+int32_t dl_max_atoms(void);
+
+/* Dynamics.forward, fully-connected graph (src/egnn.py:374-447).
+ *   xh          device [B,N,3+nf]   noisy state z_t (masked by node_mask inside, like the reference)
+ *   t           device [B] (t_is_scalar=0) or [1] (t_is_scalar=1, the numel==1 branch :397-399)
+ *   node_mask   device int8 [B,N]
+ *   linker_mask device f32 [B,N] or NULL (NULL = no masking of the coordinate update, :113-114)
+ *   edge_mask   device int8 [B,N,N] ({0,-1,-2} from collate; multiplies every message as-is) or NULL
+ *               contract: edge_mask must be 0 wherever an endpoint has node_mask 0 (datasets.py:366-369)
+ *   context     device f32 [B,N,ctx] or NULL when ctx == 0
+ *   out         device [B,N,3+nf]   eps_hat = cat[vel, h_final]; padded rows are written as 0
+ *   nan_flags   device int32 [B]    bit0: NaN in vel, bit1: NaN in h_final, bit2: too many atoms
+ *                                   (the caller raises FoundNaNException, src/egnn.py:441-442) */
+int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
+                           const float* xh, const float* t, int32_t t_is_scalar,
+                           const int8_t* node_mask, const float* linker_mask, const int8_t* edge_mask,
+                           const float* context, float* out, int32_t* nan_flags, void* stream);
+
+/* Per-step scalars of the reverse process, computed by the host exactly as the reference does
+ * (src/edm.py:180-185,199,202): one row per reverse step, in execution order (s = T-1 ... 0). */
+typedef struct dl_step_coef {
+    float t;            /* time feature (s+1)/T fed to the denoiser        */
+    float alpha_ts;     /* alpha_{t|s}                                      */
+    float c_eps;        /* sigma2_{t|s} / alpha_{t|s} / sigma_t             */
+    float sigma;        /* sigma_{t|s} * sigma_s / sigma_t                  */
+} dl_step_coef;
+
+/* Fused tail of sample_p_zs_given_zt_only_linker (src/edm.py:196-206):
+ *   z_s = z_t*frag + ((z_t/alpha_ts - c_eps*(eps_hat*lm)) + sigma*(noise*lm)) * lm
+ * z_t, eps_hat, noise, z_s: device [B,N,D]; fragment_mask/linker_mask: device f32 [B,N]. */
+int32_t dl_sampler_step(int32_t B, int32_t N, int32_t D, const float* z_t, const float* eps_hat,
+                        const float* noise, const float* fragment_mask, const float* linker_mask,
+                        dl_step_coef coef, float* z_s, void* stream);
+
+/* EDM.sample_chain (src/edm.py:126-176) as ONE launch: every molecule runs its T reverse steps
+ * and the final decode on one compute unit with its state resident in LDS. */
+typedef struct dl_chain_args {
+    int32_t B, N, T, keep_frames;
+    const float* x;             /* device [B,N,3]   fragment-centred coordinates               */
+    const float* h;             /* device [B,N,nf]  one-hot atom types (un-normalised)         */
+    const int8_t* node_mask;    /* device [B,N]                                                */
+    const float* fragment_mask; /* device [B,N]                                                */
+    const float* linker_mask;   /* device [B,N]                                                */
+    const int8_t* edge_mask;    /* device [B,N,N]                                              */
+    const float* context;       /* device [B,N,ctx]                                            */
+    const float* noise_x;       /* device [T+2,B,N,3]  standard normal draws, reference order: */
+    const float* noise_h;       /* device [T+2,B,N,nf] draw 0 = initial z, 1..T = steps, T+1 = decode */
+    const dl_step_coef* coefs;  /* device [T]       execution order (s = T-1 first)            */
+    float inv_alpha0, sigma0, sigma_x;      /* final decode scalars (src/edm.py:213-216,237-242) */
+    float norm_x, norm_h, bias_h;           /* norm_values[0], norm_values[1], norm_biases[1]    */
+    float* chain;               /* device [keep_frames,B,N,3+nf]; frame 0 = final [x, one_hot(h)] */
+    int32_t* nan_flags;         /* device [B]  bit0/bit1 as above (first offending forward only) */
+    int32_t* nan_step;          /* device [B]  forward index (0..T) at which the flag was raised, or -1 */
+} dl_chain_args;
+
+int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
+
+const char* dl_error_string(int32_t status);
+int32_t dl_last_hip_error(void);
+int32_t dl_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFLINKER_HIP_H */

@@ -1,0 +1,378 @@
+"""GPU parity tests: the HIP path (through the Python boundary -> C ABI) against the CPU oracle on the
+same seeded inputs, against the golden fixtures of the unmodified reference, and through
+size-independent properties (padding invariance, E(3) equivariance, determinism, mask semantics).
+
+Tolerances (fp32 everywhere): one ``Dynamics.forward`` rel-L2 <= 1e-5 on vel and h; a full
+``sample_chain`` with a shared noise bank rel-L2 <= 1e-4 on the linker coordinates and exact one-hot
+atom types (BASELINE.json north_star: 1e-4).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import seeded_state_dict, rel_l2, max_abs
+from oracle import edm_oracle, egnn_oracle
+from oracle.egnn_oracle import EGNNConfig
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+CHAIN_TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    return torch.device('cuda:0')
+
+
+def make_dynamics(nf, ctx, n_layers, seed, coord_gain=0.02):
+    from difflinker_amd import Dynamics
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, n_layers=n_layers,
+                   norm_constant=1e-6, normalization='batch_norm')
+    sd = seeded_state_dict(nf + ctx + 1, 128, n_layers, seed, coord_gain=coord_gain)
+    dyn.load_state_dict(sd, strict=True)
+    return dyn.to(dev()), sd, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=n_layers)
+
+
+def ragged_inputs(sizes, linkers, nf, seed, ctx=1, n_pad=None):
+    from difflinker_amd import synthetic
+    from difflinker_amd.datasets import collate
+    g = torch.Generator().manual_seed(seed)
+    mols = []
+    for n, nl in zip(sizes, linkers):
+        frag = torch.zeros(n)
+        frag[:n - nl] = 1
+        types = torch.randint(0, nf, (n,), generator=g)
+        mols.append({'positions': 2.0 * torch.randn((n, 3), generator=g),
+                     'one_hot': torch.nn.functional.one_hot(types, nf).float(),
+                     'anchors': torch.zeros(n), 'fragment_mask': frag, 'linker_mask': 1 - frag, 'num_atoms': n})
+    if n_pad is not None and n_pad > max(sizes):
+        # a dummy molecule that only forces the padded width; dropped below
+        mols.append({'positions': torch.zeros(n_pad, 3), 'one_hot': torch.zeros(n_pad, nf), 'anchors': torch.zeros(n_pad),
+                     'fragment_mask': torch.ones(n_pad), 'linker_mask': torch.zeros(n_pad), 'num_atoms': n_pad})
+    data = collate(mols)
+    if n_pad is not None and n_pad > max(sizes):
+        B = len(sizes)
+        N = n_pad
+        em = data['edge_mask'].view(B + 1, N * N)[:B].reshape(-1, 1)
+        data = {k: (v[:B] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B + 1 else v) for k, v in data.items()}
+        data['edge_mask'] = em
+    inp = synthetic.sampler_inputs(data)
+    if ctx == 2:                                     # e.g. anchors + fragment mask
+        inp['context'] = torch.cat([data['anchors'], inp['context']], dim=-1)
+    B, N = inp['x'].shape[:2]
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.randn((B, N, 3 + nf), generator=g) * inp['linker_mask']
+    t = torch.rand((B, 1), generator=g)
+    return inp, z, t
+
+
+def run_hip_forward(dyn, inp, z, t, linker_mask='given', edge_mask='given'):
+    d = dev()
+    lm = inp['linker_mask'].to(d) if linker_mask == 'given' else None
+    em = inp['edge_mask'].to(d) if edge_mask == 'given' else edge_mask
+    out = dyn.forward(t=t.to(d), xh=z.to(d), node_mask=inp['node_mask'].to(d), linker_mask=lm,
+                      edge_mask=em, context=inp['context'].to(d))
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def report(tag, out, ref):
+    ev, eh = rel_l2(out[..., :3], ref[..., :3]), rel_l2(out[..., 3:], ref[..., 3:])
+    per_mol = [(round(rel_l2(out[b, :, :3], ref[b, :, :3]), 9), round(rel_l2(out[b, :, 3:], ref[b, :, 3:]), 9))
+               for b in range(out.shape[0])]
+    print(f'[{tag}] rel-L2 vel {ev:.3e} h {eh:.3e} | max-abs {max_abs(out, ref):.3e} | per-mol {per_mol[:8]}')
+    return ev, eh
+
+
+def load_golden(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + '.npz'))
+    return {k: torch.from_numpy(z[k]) if z[k].shape != () else z[k].item() for k in z.files}
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('sizes,linkers,n_layers', [
+    ([5], [2], 1),                       # one partial tile, rows of several atoms per tile (generic reduce)
+    ([33], [5], 1),                      # two M-tiles, two-atoms-per-tile fast reduce
+    ([14, 9, 12, 5], [4, 3, 5, 2], 2),
+    ([55, 32, 31, 1, 40], [6, 3, 4, 1, 12], 2),   # LDS limit, tile boundaries, single atom
+    ([50, 35, 44], [8, 3, 12], 6),       # GEOM-sized, full depth
+])
+def test_forward_vs_oracle(sizes, linkers, n_layers):
+    nf, ctx = 9, 1
+    dyn, sd, cfg = make_dynamics(nf, ctx, n_layers, seed=100 + n_layers)
+    inp, z, t = ragged_inputs(sizes, linkers, nf, seed=sum(sizes))
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
+                                       inp['context'])
+    out = run_hip_forward(dyn, inp, z, t)
+    ev, eh = report(f'fwd sizes={sizes} L={n_layers}', out, ref)
+    nm = inp['node_mask'].float()
+    assert float((out * (1 - nm)).abs().max()) == 0.0, 'padded rows must be exactly zero'
+    assert ev <= FWD_TOL and eh <= FWD_TOL
+
+
+def test_forward_vs_reference_golden(golden_dir):
+    g = load_golden(golden_dir, 'fc_forward')
+    dyn, sd, cfg = make_dynamics(g['nf'], g['ctx'], g['n_layers'], seed=g['weight_seed'], coord_gain=g['coord_gain'])
+    inp = {k: g[k] for k in ('node_mask', 'linker_mask', 'edge_mask', 'context')}
+    out = run_hip_forward(dyn, inp, g['xh'], g['t'])
+    ev, eh = report('golden fc_forward', out, g['out'])
+    assert ev <= FWD_TOL and eh <= FWD_TOL
+    # scalar-t branch (egnn.py:397-399) on the un-padded molecule 1
+    B, N = g['xh'].shape[:2]
+    inp1 = {'node_mask': g['node_mask'][1:2, :9], 'linker_mask': g['linker_mask'][1:2, :9],
+            'edge_mask': g['edge_mask'].view(B, N, N)[1, :9, :9].reshape(-1, 1), 'context': g['context'][1:2, :9]}
+    out1 = run_hip_forward(dyn, inp1, g['xh'][1:2, :9], g['t'][1:2])
+    ev, eh = report('golden fc_forward mol1 unpadded', out1, g['out_mol1_unpadded'])
+    assert ev <= FWD_TOL and eh <= FWD_TOL
+
+
+@pytest.mark.parametrize('nf,ctx', [(8, 1), (9, 2)])
+def test_forward_feature_widths(nf, ctx):
+    dyn, sd, cfg = make_dynamics(nf, ctx, 2, seed=7)
+    inp, z, t = ragged_inputs([20, 17], [5, 4], nf, seed=3, ctx=ctx)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
+                                       inp['context'])
+    ev, eh = report(f'fwd nf={nf} ctx={ctx}', run_hip_forward(dyn, inp, z, t), ref)
+    assert ev <= FWD_TOL and eh <= FWD_TOL
+
+
+def test_forward_without_linker_mask_and_wide_padding():
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=8)
+    inp, z, t = ragged_inputs([10, 22], [3, 6], nf, seed=5, n_pad=70)       # N=70 > 64: multi-chunk compaction
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], None, inp['edge_mask'], inp['context'])
+    ev, eh = report('fwd linker_mask=None N=70', run_hip_forward(dyn, inp, z, t, linker_mask=None), ref)
+    assert ev <= FWD_TOL and eh <= FWD_TOL
+
+
+def test_padding_invariance_is_exact():
+    """A molecule gives bitwise the same eps_hat alone/un-padded and inside a padded batch."""
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=9)
+    inp, z, t = ragged_inputs([30, 12, 21], [5, 4, 6], nf, seed=6)
+    full = run_hip_forward(dyn, inp, z, t)
+    B, N = z.shape[:2]
+    for b, n in enumerate([30, 12, 21]):
+        sub = {'node_mask': inp['node_mask'][b:b + 1, :n], 'linker_mask': inp['linker_mask'][b:b + 1, :n],
+               'edge_mask': inp['edge_mask'].view(B, N, N)[b, :n, :n].reshape(-1, 1),
+               'context': inp['context'][b:b + 1, :n]}
+        alone = run_hip_forward(dyn, sub, z[b:b + 1, :n], t[b:b + 1])
+        assert torch.equal(alone[0], full[b, :n]), f'molecule {b}'
+
+
+def test_determinism_bitwise():
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 3, seed=10)
+    inp, z, t = ragged_inputs([50, 37, 44, 9], [8, 3, 12, 2], nf, seed=7)
+    a = run_hip_forward(dyn, inp, z, t)
+    for _ in range(3):
+        assert torch.equal(run_hip_forward(dyn, inp, z, t), a)
+
+
+def test_rotation_equivariance_and_translation():
+    """vel rotates with x, h_final is invariant (E(3) property of egnn.py:295-301,101-117)."""
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 3, seed=11)
+    inp, z, t = ragged_inputs([28, 41], [6, 9], nf, seed=8)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    zr = z.clone()
+    zr[..., :3] = z[..., :3] @ q.T
+    a, b = run_hip_forward(dyn, inp, z, t), run_hip_forward(dyn, inp, zr, t)
+    e_vel = rel_l2(b[..., :3], a[..., :3] @ q.T)
+    e_h = rel_l2(b[..., 3:], a[..., 3:])
+    print(f'[equivariance] vel {e_vel:.3e} h {e_h:.3e}')
+    assert e_vel <= 1e-4 and e_h <= 1e-4
+    zt = z.clone()
+    zt[..., :3] = (z[..., :3] + torch.tensor([1.5, -2.0, 0.75])) * inp['node_mask'].float()
+    c = run_hip_forward(dyn, inp, zt, t)
+    assert rel_l2(c, a) <= 1e-4
+
+
+def test_edge_mask_sign_convention_is_observable():
+    """The int8 {0,-1,-2} mask multiplies messages as-is; a boolean {0,1} off-diagonal mask gives a
+    different answer on both the oracle and the HIP path."""
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=12)
+    inp, z, t = ragged_inputs([18, 25], [4, 6], nf, seed=9)
+    B, N = z.shape[:2]
+    nm = inp['node_mask'].view(B, N).to(torch.int8)
+    bool_mask = (nm[:, None, :] * nm[:, :, None]) * (1 - torch.eye(N, dtype=torch.int8))
+    bool_mask = bool_mask.view(-1, 1)
+    ref_i8 = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    ref_bool = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], bool_mask, inp['context'])
+    out_i8 = run_hip_forward(dyn, inp, z, t)
+    out_bool = run_hip_forward(dyn, inp, z, t, edge_mask=bool_mask.to(dev()))
+    assert rel_l2(ref_bool, ref_i8) > 1e-3
+    assert rel_l2(out_i8, ref_i8) <= FWD_TOL and rel_l2(out_bool, ref_bool) <= FWD_TOL
+
+
+def test_nan_raises_found_nan_exception_with_index_sets():
+    from difflinker_amd import FoundNaNException
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=13)
+    inp, z, t = ragged_inputs([12, 15, 9], [3, 4, 2], nf, seed=10)
+    z = z.clone()
+    z[1, 2, 0] = float('nan')          # coordinate NaN in molecule 1 -> radial NaN -> both vel and h
+    with pytest.raises(FoundNaNException) as ei:
+        run_hip_forward(dyn, inp, z, t)
+    with pytest.raises(egnn_oracle.OracleNaN) as eo:
+        egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    assert ei.value.x_h_nan_idx == eo.value.x_h_nan_idx == {1}
+    assert ei.value.only_x_nan_idx == eo.value.only_x_nan_idx
+    assert ei.value.only_h_nan_idx == eo.value.only_h_nan_idx
+
+
+def test_too_many_atoms_is_an_error_not_a_fallback():
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=14)
+    inp, z, t = ragged_inputs([56, 10], [5, 2], nf, seed=11)
+    with pytest.raises(ValueError, match='real atoms'):
+        run_hip_forward(dyn, inp, z, t)
+
+
+def test_sampler_step_kernel_matches_oracle_arithmetic():
+    from difflinker_amd import EDM, _lib
+    nf = 8
+    dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=15)
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+              loss_type='l2', norm_values=[1, 4, 10])
+    g = torch.Generator().manual_seed(2)
+    B, N, D = 5, 13, 3 + nf
+    z_t, eps, noise = (torch.randn((B, N, D), generator=g) for _ in range(3))
+    lm = (torch.rand((B, N, 1), generator=g) > 0.5).float()
+    fm = 1 - lm
+    coefs, _ = edm.step_coefficients(B)
+    t_, a_, c_, s_ = (float(v) for v in coefs[40])
+    want = z_t * fm + ((z_t / a_ - c_ * (eps * lm)) + s_ * (noise * lm)) * lm
+    d = dev()
+    got = edm._sampler_step(z_t.to(d), eps.to(d), noise.to(d), fm.to(d), lm.to(d), _lib.DLStepCoef(t_, a_, c_, s_)).cpu()
+    assert max_abs(got, want) <= 2e-6 * float(want.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------
+def chain_case(nf, n_layers, sizes, linkers, T, keep, seed, timesteps=500):
+    from difflinker_amd import EDM
+    dyn, sd, cfg = make_dynamics(nf, 1, n_layers, seed=seed)
+    inp, _, _ = ragged_inputs(sizes, linkers, nf, seed=seed + 1)
+    B, N = inp['x'].shape[:2]
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=timesteps, noise_schedule='polynomial_2',
+              noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10]).to(dev())
+    edm.T = T
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=seed + 2)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=timesteps)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                            inp['edge_mask'], inp['context'], bank, keep_frames=keep)
+    g = {k: v.to(dev()) for k, v in inp.items()}
+    got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
+                           g['context'], keep_frames=keep, noise_bank=bank.stacked()).cpu()
+    return got, want, inp
+
+
+def check_chain(tag, got, want, inp):
+    assert got.shape == want.shape
+    lm = inp['linker_mask']
+    ex = rel_l2(got[0, :, :, :3] * lm, want[0, :, :, :3] * lm)
+    mism = int((got[0, :, :, 3:] != want[0, :, :, 3:]).any(-1).sum())
+    efr = rel_l2(got[1:], want[1:]) if got.shape[0] > 1 else 0.0
+    print(f'[{tag}] final linker-x rel-L2 {ex:.3e}, one-hot mismatches {mism}, other frames rel-L2 {efr:.3e}')
+    assert ex <= CHAIN_TOL and efr <= CHAIN_TOL
+    assert mism == 0
+    fm = inp['fragment_mask']
+    assert max_abs(got[0, :, :, :3] * fm, want[0, :, :, :3] * fm) <= 1e-6     # fragments never move
+
+
+def test_chain_vs_oracle_short():
+    got, want, inp = chain_case(nf=8, n_layers=2, sizes=[12, 7, 10], linkers=[4, 2, 3], T=12, keep=3, seed=40)
+    check_chain('chain T=12', got, want, inp)
+
+
+def test_chain_vs_reference_golden(golden_dir):
+    from difflinker_amd import EDM
+    g = load_golden(golden_dir, 'fc_chain')
+    dyn, sd, cfg = make_dynamics(g['nf'], g['ctx'], g['n_layers'], seed=g['weight_seed'], coord_gain=g['coord_gain'])
+    edm = EDM(dyn, in_node_nf=g['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+              noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10]).to(dev())
+    edm.T = g['T']
+    d = dev()
+    got = edm.sample_chain(g['x'].to(d), g['h'].to(d), g['node_mask'].to(d), g['fragment_mask'].to(d),
+                           g['linker_mask'].to(d), g['edge_mask'].to(d), g['context'].to(d),
+                           keep_frames=g['keep_frames'], noise_bank=(g['noise_x'], g['noise_h'])).cpu()
+    check_chain('golden fc_chain', got, g['chain'], {'linker_mask': g['linker_mask'], 'fragment_mask': g['fragment_mask']})
+
+
+def test_chain_keep_frames_all_and_one():
+    for keep in (1, 20):
+        got, want, inp = chain_case(nf=9, n_layers=1, sizes=[16, 9], linkers=[4, 3], T=20, keep=keep, seed=50)
+        check_chain(f'chain T=20 keep={keep}', got, want, inp)
+
+
+def test_chain_T_differs_from_table_length():
+    """--n_steps only overwrites edm.T; the gamma table keeps its trained length (generate.py:103-104)."""
+    got, want, inp = chain_case(nf=8, n_layers=1, sizes=[10, 13], linkers=[3, 4], T=7, keep=2, seed=60, timesteps=1000)
+    check_chain('chain T=7 on 1000-entry table', got, want, inp)
+
+
+def test_chain_full_length_zinc_like():
+    """C1-like: ZINC hparams (8 blocks), T=50 on the 500-entry table, B=8, N=30."""
+    from difflinker_amd import synthetic
+    got, want, inp = chain_case(nf=8, n_layers=8, sizes=[30, 24, 27, 29, 25, 30, 26, 28],
+                                linkers=[5, 3, 8, 4, 6, 7, 3, 5], T=50, keep=1, seed=70)
+    check_chain('chain C1-like T=50 L=8', got, want, inp)
+
+
+def test_ddpm_sample_chain_end_to_end():
+    """DDPM.sample_chain: templates -> context -> COM removal -> fused chain (lightning.py:405-463)."""
+    from difflinker_amd import DDPM, synthetic
+    hp = dict(in_node_nf=8, n_dims=3, context_node_nf=1, hidden_nf=128, activation='silu', tanh=False, n_layers=2,
+              attention=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+              aggregation_method='sum', diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+              diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4, 10],
+              include_charges=False, model='egnn_dynamics', data_path='d', train_data_prefix='zinc_final_train',
+              val_data_prefix='zinc_final_val', batch_size=8, lr=2e-4, torch_device='cuda:0', test_epochs=20,
+              n_stability_samples=10, normalization='batch_norm', anchors_context=False)
+    torch.manual_seed(0)
+    m = DDPM(**hp).to(dev()).eval()
+    m.edm.T = 6
+    data, cfg = synthetic.make_batch('C1', seed=2, batch=4, device=dev())
+    torch.manual_seed(123)
+    chain, node_mask = m.sample_chain(data, keep_frames=1)
+    torch.manual_seed(123)
+    chain2, _ = m.sample_chain(data, keep_frames=1)
+    assert chain.shape == (1, 4, data['positions'].shape[1], 11)
+    assert torch.equal(chain, chain2), 'same torch seed -> same sample'
+    x, h = chain[0][..., :3], chain[0][..., 3:]
+    nm = node_mask.float()
+    assert torch.isfinite(chain).all()
+    assert float((chain[0] * (1 - nm)).abs().max()) == 0.0
+    assert torch.equal(h.sum(-1), nm.squeeze(-1)), 'one-hot rows for real atoms, zero rows for padding'
+    # fragments keep their (centred) input coordinates
+    from difflinker_amd import utils
+    x_in = utils.remove_partial_mean_with_mask(data['positions'] * data['fragment_mask'], nm, data['fragment_mask'])
+    fm = data['fragment_mask']
+    assert max_abs((x * fm).cpu(), (x_in * fm).cpu()) <= 1e-5
+
+
+def test_geom_sized_forward_full_batch():
+    """BASELINE config C2 at full size (B=256, N=50, 6 blocks): one forward against the oracle."""
+    from difflinker_amd import synthetic
+    nf, L = 9, 6
+    dyn, sd, cfg = make_dynamics(nf, 1, L, seed=80)
+    data, c2 = synthetic.make_batch('C2', seed=1)
+    inp = synthetic.sampler_inputs(data)
+    B, N = inp['x'].shape[:2]
+    g = torch.Generator().manual_seed(4)
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.randn((B, N, 3 + nf), generator=g) * inp['linker_mask']
+    t = torch.full((B, 1), 0.37)
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    out = run_hip_forward(dyn, inp, z, t)
+    ev, eh = report('C2 full forward', out, ref)
+    assert ev <= FWD_TOL and eh <= FWD_TOL

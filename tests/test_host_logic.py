@@ -1,0 +1,196 @@
+"""CPU tests of the host side: C-ABI library exports, parameter containers / checkpoint keys,
+per-step scalar tables, DDPM glue, batch sharding (gloo, world_size 2)."""
+import ctypes
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from helpers import dynamics_param_shapes, seeded_state_dict, rel_l2
+from oracle import edm_oracle, egnn_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from difflinker_amd import _lib
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, 'include', 'difflinker_hip.h')).read()
+    declared = set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', header))
+    declared -= {'dl_max_atoms'} - {'dl_max_atoms'}
+    assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dl_abi_version() == 1
+    assert lib.dl_max_atoms() == 55
+    assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
+    cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0)
+    assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == 4 + 6 * 21
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    from difflinker_amd import Dynamics
+    dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+    xh = torch.zeros(1, 4, 12)
+    with pytest.raises(RuntimeError, match='GPU only'):
+        dyn.forward(torch.zeros(1, 1), xh, torch.ones(1, 4, 1, dtype=torch.int8), torch.ones(1, 4, 1),
+                    torch.ones(16, 1, dtype=torch.int8), torch.ones(1, 4, 1))
+
+
+def test_unsupported_hparams_raise():
+    from difflinker_amd import Dynamics
+    for kw in (dict(attention=True), dict(tanh=True), dict(sin_embedding=True), dict(aggregation_method='mean'),
+               dict(hidden_nf=64), dict(model='gnn_dynamics')):
+        args = dict(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1)
+        args.update(kw)
+        with pytest.raises(NotImplementedError):
+            Dynamics(**args)
+
+
+def test_state_dict_keys_and_tensor_order():
+    from difflinker_amd import Dynamics
+    from difflinker_amd.egnn import egnn_tensor_order
+    dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=3, norm_constant=1e-6)
+    expect = dynamics_param_shapes(11, 128, 3)
+    sd = dyn.state_dict()
+    assert list(sd.keys()) == [k for k, *_ in expect]
+    for k, shape, *_ in expect:
+        assert tuple(sd[k].shape) == shape
+    order = egnn_tensor_order(3)
+    assert sorted('dynamics.' + k for k in order) == sorted(sd.keys())
+    dyn.load_state_dict(seeded_state_dict(11, 128, 3, seed=1), strict=True)
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/src'), reason='reference tree only exists in the build container')
+def test_same_seed_same_init_as_reference():
+    sys.path.insert(0, '/root/reference')
+    sys.dont_write_bytecode = True
+    from src.egnn import Dynamics as RefDynamics
+    from difflinker_amd import Dynamics
+    kw = dict(n_dims=3, in_node_nf=8, context_node_nf=1, hidden_nf=128, n_layers=2, norm_constant=1e-6)
+    torch.manual_seed(7)
+    ref = RefDynamics(**kw)
+    torch.manual_seed(7)
+    ours = Dynamics(**kw)
+    a, b = ref.state_dict(), ours.state_dict()
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_step_coefficients_match_oracle_scalars():
+    from difflinker_amd import Dynamics, EDM
+    dyn = Dynamics(3, 8, 1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+    for T in (500, 50, 12):
+        edm = EDM(dyn, in_node_nf=8, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+                  loss_type='l2', norm_values=[1, 4, 10])
+        edm.T = T
+        coefs, (inv_a0, s0, sx) = edm.step_coefficients()
+        orc = edm_oracle.EDMOracle(None, in_node_nf=8, timesteps=500)
+        orc.T = T
+        assert torch.equal(edm.gamma.gamma.data, orc.gamma_table)
+        z = torch.zeros(1, 1, 1)
+        for q, s in enumerate(reversed(range(T))):
+            s_arr = torch.full((1, 1), s) / T
+            t_arr = (torch.full((1, 1), s) + 1) / T
+            g_s, g_t = orc.gamma(s_arr), orc.gamma(t_arr)
+            s2, s_ts, a_ts = orc.sigma_and_alpha_t_given_s(g_t, g_s, z)
+            want = torch.stack([t_arr.view(()), a_ts.view(()), (s2 / a_ts / orc.sigma(g_t, z)).view(()),
+                                (s_ts * orc.sigma(g_s, z) / orc.sigma(g_t, z)).view(())])
+            assert torch.equal(coefs[q], want), (T, q)
+        g0 = orc.gamma(torch.zeros(1, 1))
+        assert abs(sx - float(torch.exp(0.5 * g0))) < 1e-9
+        assert abs(inv_a0 - float(1. / orc.alpha(g0, z))) < 1e-7 and abs(s0 - float(orc.sigma(g0, z))) < 1e-9
+
+
+def test_ddpm_checkpoint_roundtrip(tmp_path):
+    from difflinker_amd import DDPM
+    hp = dict(in_node_nf=8, n_dims=3, context_node_nf=1, hidden_nf=128, activation='silu', tanh=False, n_layers=2,
+              attention=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+              aggregation_method='sum', diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+              diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4, 10],
+              include_charges=False, model='egnn_dynamics', data_path='d', train_data_prefix='zinc_final_train',
+              val_data_prefix='zinc_final_val', batch_size=8, lr=2e-4, torch_device='cpu', test_epochs=20,
+              n_stability_samples=10, normalization='batch_norm', anchors_context=False)
+    torch.manual_seed(3)
+    m = DDPM(**hp)
+    keys = list(m.state_dict().keys())
+    assert keys[0] == 'edm.gamma.gamma' and 'edm.dynamics.dynamics.embedding.weight' in keys
+    assert 'edm.dynamics.dynamics.e_block_1.gcl_equiv.coord_mlp.4.weight' in keys
+    path = tmp_path / 'm.ckpt'
+    torch.save(m.checkpoint_dict(), path)
+    m2 = DDPM.load_from_checkpoint(str(path), map_location='cpu')
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+    assert m2.edm.T == 500 and not m2.is_geom and m2.center_of_mass == 'fragments'
+
+
+def _gloo_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from difflinker_amd import synthetic
+    from difflinker_amd.distributed import sample_chain_sharded, shard_bounds
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    data, cfg = synthetic.make_batch('C1', seed=9, batch=5)
+    inp = synthetic.sampler_inputs(data)
+    nf, L, T = cfg['nf'], 1, 3
+    sd = seeded_state_dict(nf + 2, 128, L, seed=4)
+    ocfg = egnn_oracle.EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=L)
+    B, N = inp['x'].shape[:2]
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=6)
+
+    class OracleEDM:
+        """Stand-in with the product EDM's sample_chain signature (the HIP EDM needs a GPU)."""
+        def sample_chain(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames=None,
+                         noise_bank=None):
+            o = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, ocfg), in_node_nf=nf, timesteps=500)
+            o.T = T
+            draws = []
+            for k in range(T + 2):
+                draws += [noise_bank[0][k], noise_bank[1][k]]
+            return o.sample_chain(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
+                                  edm_oracle.NoiseBank(draws), keep_frames=keep_frames)
+
+    full = sample_chain_sharded(OracleEDM(), inp, keep_frames=2, noise_bank=bank.stacked())
+    lo, hi = shard_bounds(B, rank, world)
+    assert (hi - lo) in (2, 3)
+    if rank == 0:
+        torch.save(full, os.path.join(tmp, 'sharded.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_chain_equals_single_process_gloo(tmp_path):
+    """world_size-2 run (gloo, CPU) of the sharding + all-gather path == unsharded oracle chain."""
+    from difflinker_amd import synthetic
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(os.path.join(str(tmp_path), 'sharded.pt'))
+    data, cfg = synthetic.make_batch('C1', seed=9, batch=5)
+    inp = synthetic.sampler_inputs(data)
+    nf, L, T = cfg['nf'], 1, 3
+    sd = seeded_state_dict(nf + 2, 128, L, seed=4)
+    ocfg = egnn_oracle.EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=L)
+    B, N = inp['x'].shape[:2]
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=6)
+    o = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, ocfg), in_node_nf=nf, timesteps=500)
+    o.T = T
+    want = o.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                          inp['edge_mask'], inp['context'], bank, keep_frames=2)
+    assert got.shape == want.shape
+    assert torch.equal(got, want)      # per-molecule arithmetic is batch-independent on the oracle
+
+
+def test_shard_bounds_cover_batch():
+    from difflinker_amd.distributed import shard_bounds
+    for n in (1, 5, 8, 256, 2048):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
