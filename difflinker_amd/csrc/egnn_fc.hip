@@ -172,12 +172,26 @@ __device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, 
 // One pass over all n_b^2 ordered pairs of the molecule.
 //   EQUIV = false: agg[i][f] += m_ij * u2_ij[f]           (GCL message sum, into v.C)
 //   EQUIV = true : aggx[i]   += cdiff_ij * (w7'.u2_ij) * m_ij (coordinate head, into v.aggx)
+// Pairs are flattened p = i*n_b + j and cut into tiles of 32; wave w takes the contiguous tile range
+// [w*ntiles/8, (w+1)*ntiles/8).  The sum over j is DETERMINISTIC: every aggregate row i is written
+// by exactly one wave — the one for which atom i is not the first atom of its range; a wave's
+// contribution to its first atom (which the previous wave may share) is kept in registers
+// (`spill`) and folded in afterwards in wave order (spill_reduce_*).  spill_row = -1: nothing.
+struct Spill {
+    int row;
+    float v[4];
+};
+
 template <bool EQUIV>
-__device__ __forceinline__ void edge_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask,
-                                           int N, float norm_constant) {
+__device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask,
+                                            int N, float norm_constant) {
     const int c = lane & 31, hh = lane >> 5;
     const int npairs = nb * nb;
     const int ntiles = (npairs + 31) >> 5;
+    const int t_begin = (w * ntiles) / NWAVES, t_end = ((w + 1) * ntiles) / NWAVES;
+    Spill sp;
+    sp.row = (w > 0 && t_begin < t_end) ? (32 * t_begin) / nb : -1;
+    sp.v[0] = sp.v[1] = sp.v[2] = sp.v[3] = 0.0f;
     float bias[4], w7[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -188,12 +202,14 @@ __device__ __forceinline__ void edge_phase(const Lds& v, int nb, int w, int lane
     const float4* wdp = reinterpret_cast<const float4*>(v.vec + HID + 64 * hh);
     const float4* Wp = reinterpret_cast<const float4*>(v.W) + (64 * hh * 32 + c);
 
-    for (int t = w; t < ntiles; t += NWAVES) {
+    for (int t = t_begin; t < t_end; ++t) {
         const int p = 32 * t + c;
         const bool valid = p < npairs;
         const int pp = valid ? p : 0;
         const int i = pp / nb;
         const int j = pp - i * nb;
+        const int i_first = (32 * t) / nb;                       // wave-uniform
+        const int i_last = min(32 * t + 31, npairs - 1) / nb;    // wave-uniform
         const float4 xi = *reinterpret_cast<const float4*>(v.xs + 4 * i);
         const float4 xj = *reinterpret_cast<const float4*>(v.xs + 4 * j);
         const float4 yi = *reinterpret_cast<const float4*>(v.x0 + 4 * i);
@@ -231,44 +247,37 @@ __device__ __forceinline__ void edge_phase(const Lds& v, int nb, int w, int lane
         }
         // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
         if (!EQUIV) {
-            const int i_first = __builtin_amdgcn_readfirstlane(i);
-            const bool two_rows = __all(!valid || i <= i_first + 1);
-            if (two_rows) {
-                // all pairs of the tile belong to atom i_first or i_first+1: pre-reduce in registers
-                float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+            float mr[16];
+            int ir[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = acc_row(reg, hh);
+                mr[reg] = __shfl(m, row);
+                ir[reg] = __shfl(i, row);
+                acc0[reg] = silu_u(acc0[reg]);
+                acc1[reg] = silu_u(acc1[reg]);
+                acc2[reg] = silu_u(acc2[reg]);
+                acc3[reg] = silu_u(acc3[reg]);
+            }
+            for (int ii = i_first; ii <= i_last; ++ii) {         // 1-2 atoms per tile when n_b >= 32
+                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const int row = acc_row(reg, hh);
-                    const float mr = __shfl(m, row);
-                    const int ir = __shfl(i, row);
-                    const float m0 = (ir == i_first) ? mr : 0.0f;
-                    const float m1 = mr - m0;
-                    const float u0 = silu_u(acc0[reg]), u1 = silu_u(acc1[reg]);
-                    const float u2 = silu_u(acc2[reg]), u3 = silu_u(acc3[reg]);
-                    s0[0] = fmaf(m0, u0, s0[0]); s1[0] = fmaf(m1, u0, s1[0]);
-                    s0[1] = fmaf(m0, u1, s0[1]); s1[1] = fmaf(m1, u1, s1[1]);
-                    s0[2] = fmaf(m0, u2, s0[2]); s1[2] = fmaf(m1, u2, s1[2]);
-                    s0[3] = fmaf(m0, u3, s0[3]); s1[3] = fmaf(m1, u3, s1[3]);
+                    const float wgt = (ir[reg] == ii) ? mr[reg] : 0.0f;
+                    s0 = fmaf(wgt, acc0[reg], s0);
+                    s1 = fmaf(wgt, acc1[reg], s1);
+                    s2 = fmaf(wgt, acc2[reg], s2);
+                    s3 = fmaf(wgt, acc3[reg], s3);
                 }
-                float* d0p = v.C + i_first * LDH + c;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) atomicAdd(d0p + 32 * nt, s0[nt]);
-                if (i_first + 1 < nb) {
-                    float* d1p = d0p + LDH;
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) atomicAdd(d1p + 32 * nt, s1[nt]);
-                }
-            } else {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = acc_row(reg, hh);
-                    const float mr = __shfl(m, row);
-                    const int ir = __shfl(i, row);
-                    float* dst = v.C + ir * LDH + c;
-                    atomicAdd(dst, mr * silu_u(acc0[reg]));
-                    atomicAdd(dst + 32, mr * silu_u(acc1[reg]));
-                    atomicAdd(dst + 64, mr * silu_u(acc2[reg]));
-                    atomicAdd(dst + 96, mr * silu_u(acc3[reg]));
+                s0 += __shfl_xor(s0, 32);
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                s3 += __shfl_xor(s3, 32);
+                if (ii == sp.row) {
+                    sp.v[0] += s0; sp.v[1] += s1; sp.v[2] += s2; sp.v[3] += s3;
+                } else if (hh == 0) {
+                    float* dst = v.C + ii * LDH + c;                 // only this wave ever touches row ii here
+                    dst[0] += s0; dst[32] += s1; dst[64] += s2; dst[96] += s3;
                 }
             }
         } else {
@@ -296,13 +305,54 @@ __device__ __forceinline__ void edge_phase(const Lds& v, int nb, int w, int lane
                 const float vv = __shfl(srow[reg], src_lane);
                 s_own = (reg == my_reg) ? vv : s_own;
             }
-            if (hh == 0 && valid) {
-                // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
-                const float den = sqrtf(r + 1e-8f) + norm_constant;
-                const float f = s_own * m;
-                atomicAdd(v.aggx + 4 * i + 0, (dx / den) * f);
-                atomicAdd(v.aggx + 4 * i + 1, (dy / den) * f);
-                atomicAdd(v.aggx + 4 * i + 2, (dz / den) * f);
+            // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
+            const float den = sqrtf(r + 1e-8f) + norm_constant;
+            const float f = (hh == 0 && valid) ? s_own * m : 0.0f;
+            const float tx = (dx / den) * f, ty = (dy / den) * f, tz = (dz / den) * f;
+            for (int ii = i_first; ii <= i_last; ++ii) {
+                float ax = (i == ii) ? tx : 0.0f, ay = (i == ii) ? ty : 0.0f, az = (i == ii) ? tz : 0.0f;
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {            // fixed-order sum over the 32 pair lanes
+                    ax += __shfl_xor(ax, off);
+                    ay += __shfl_xor(ay, off);
+                    az += __shfl_xor(az, off);
+                }
+                if (ii == sp.row) {
+                    sp.v[0] += ax; sp.v[1] += ay; sp.v[2] += az;
+                } else if (lane == 0) {
+                    v.aggx[4 * ii + 0] += ax; v.aggx[4 * ii + 1] += ay; v.aggx[4 * ii + 2] += az;
+                }
+            }
+        }
+    }
+    return sp;
+}
+
+// fold the per-wave first-atom partial sums into the aggregate, in wave order (deterministic).
+// Staging area: the first NWAVES rows of v.A (P is dead once every wave has left the edge phase).
+__device__ __forceinline__ void spill_publish(const Lds& v, const Spill& sp, int w, int lane, bool equiv) {
+    const int c = lane & 31, hh = lane >> 5;
+    if (lane == 0) v.misc[4 + w] = sp.row;
+    if (sp.row >= 0) {
+        if (!equiv) {
+            if (hh == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) v.A[w * LDH + 32 * nt + c] = sp.v[nt];
+            }
+        } else if (lane == 0) {
+            v.A[w * LDH + 0] = sp.v[0]; v.A[w * LDH + 1] = sp.v[1]; v.A[w * LDH + 2] = sp.v[2];
+        }
+    }
+}
+
+__device__ __forceinline__ void spill_reduce(const Lds& v, int tid, bool equiv) {
+    const int width = equiv ? 3 : HID;
+    if (tid < width) {
+        for (int w = 1; w < NWAVES; ++w) {
+            const int row = v.misc[4 + w];
+            if (row >= 0) {
+                if (!equiv) v.C[row * LDH + tid] += v.A[w * LDH + tid];
+                else v.aggx[4 * row + tid] += v.A[w * LDH + tid];
             }
         }
     }
@@ -319,8 +369,12 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
     __syncthreads();                       // P, Q, W2', vectors in place; every read of H (v.C) done
     for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
     __syncthreads();
-    edge_phase<false>(v, nb, w, lane, emask, N, 0.0f);
-    __syncthreads();                       // aggregate complete in v.C; P (v.A), Q (v.B) dead
+    const Spill sp = edge_phase<false>(v, nb, w, lane, emask, N, 0.0f);
+    __syncthreads();                       // every wave left the edge phase: P (v.A), Q (v.B) dead
+    spill_publish(v, sp, w, lane, false);
+    __syncthreads();
+    spill_reduce(v, tid, false);
+    __syncthreads();                       // aggregate complete in v.C
     const bool active = (mt == 0) || (nb > 32);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
@@ -367,7 +421,11 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w,
     node_pre(v, nb, w, lane, e + E_W5A, e + E_W5B, vecs);
     if (tid < 4 * nb) v.aggx[tid] = 0.0f;
     __syncthreads();
-    edge_phase<true>(v, nb, w, lane, emask, N, norm_constant);
+    const Spill sp = edge_phase<true>(v, nb, w, lane, emask, N, norm_constant);
+    __syncthreads();
+    spill_publish(v, sp, w, lane, true);
+    __syncthreads();
+    spill_reduce(v, tid, true);
     __syncthreads();
     if (tid < 4 * nb && (tid & 3) < 3) v.xs[tid] += v.aggx[tid] * v.lm[tid >> 2];
     __syncthreads();

@@ -98,7 +98,7 @@ def load_golden(golden_dir, name):
     ([5], [2], 1),                       # one partial tile, rows of several atoms per tile (generic reduce)
     ([33], [5], 1),                      # two M-tiles, two-atoms-per-tile fast reduce
     ([14, 9, 12, 5], [4, 3, 5, 2], 2),
-    ([55, 32, 31, 1, 40], [6, 3, 4, 1, 12], 2),   # LDS limit, tile boundaries, single atom
+    ([55, 32, 31, 2, 40], [6, 3, 4, 1, 12], 2),   # LDS limit, tile boundaries, one fragment + one linker atom
     ([50, 35, 44], [8, 3, 12], 6),       # GEOM-sized, full depth
 ])
 def test_forward_vs_oracle(sizes, linkers, n_layers):
