@@ -44,7 +44,8 @@ class DLChainArgs(ctypes.Structure):
 
 
 EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_string', 'dl_model_num_tensors',
-           'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc')
+           'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
+           'dl_set_profile_buffer', 'dl_profile_max_events')
 
 _lib = None
 
@@ -82,6 +83,9 @@ def load():
     lib.dl_egnn_forward_fc.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.dl_sampler_step.restype = i32
     lib.dl_sampler_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, DLStepCoef, vp, vp]
+    lib.dl_set_profile_buffer.restype = None
+    lib.dl_set_profile_buffer.argtypes = [vp]
+    lib.dl_profile_max_events.restype = i32
     lib.dl_sample_chain_fc.restype = i32
     lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
     _lib = lib

@@ -99,6 +99,25 @@ struct ModelDims {
     float norm_constant;
 };
 
+// Optional phase timeline (diagnostics, dl_set_profile_buffer): lane 0 of every wave of block 0 logs
+// (tag, s_memtime) pairs into buf[wave][event][2]; buf == nullptr (the normal case) costs one
+// wave-uniform branch per phase.
+constexpr int PROF_MAX_EVENTS = 512;
+struct Prof {
+    unsigned long long* buf;
+    int n;
+};
+__device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
+    if (pf.buf != nullptr) {
+        if (lane == 0 && pf.n < PROF_MAX_EVENTS) {
+            unsigned long long* e = pf.buf + (size_t(w) * PROF_MAX_EVENTS + pf.n) * 2;
+            e[0] = (unsigned long long)tag;
+            e[1] = __builtin_amdgcn_s_memtime();
+        }
+        pf.n++;
+    }
+}
+
 // u = y * sigmoid(-y / log2e)  ==  -log2(e) * SiLU(pre)  for  y = -log2(e) * pre
 __device__ __forceinline__ float silu_u(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
@@ -118,49 +137,64 @@ __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
 // row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
-// acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.
-// A: LDS row `arow` of a [n][LDH] tile; this lane supplies k = 64*hh + s.
-// B: packed unit slice for one 32-feature tile, fragment order [sg][lane][4] (L2-resident).
-__device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh,
-                                          const float* __restrict__ unit_nt, int lane) {
-    const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
+// B fragments of one packed unit slice (one 32-feature tile, K = 128): 16 x dwordx4 per lane from L2.
+struct BFrag {
+    float4 q[16];
+};
+__device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, int lane) {
+    BFrag b;
     const float4* bp = reinterpret_cast<const float4*>(unit_nt) + lane;
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) b.q[sg] = bp[sg * 64];
+    return b;
+}
+
+// acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.
+// A: LDS row `arow` of a [n][LDH] tile; this lane supplies k = 64*hh + s.  B: pre-loaded fragments.
+__device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh, const BFrag& b) {
+    const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
 #pragma unroll
     for (int sg = 0; sg < 16; ++sg) {
         const float4 a = ap[sg];
-        const float4 b = bp[sg * 64];
-        acc = mfma32(a.x, b.x, acc);
-        acc = mfma32(a.y, b.y, acc);
-        acc = mfma32(a.z, b.z, acc);
-        acc = mfma32(a.w, b.w, acc);
+        acc = mfma32(a.x, b.q[sg].x, acc);
+        acc = mfma32(a.y, b.q[sg].y, acc);
+        acc = mfma32(a.z, b.q[sg].z, acc);
+        acc = mfma32(a.w, b.q[sg].w, acc);
     }
 }
 
-// copy the [k][c][nt] image of a 128x128 matrix and `nvec` 128-vectors from L2 into LDS
-__device__ __forceinline__ void stage_edge_weights(const Lds& v, const float* __restrict__ wimg,
-                                                   const float* __restrict__ vecs, int nvec, int tid) {
+// copy the [k][c][nt] image of a 128x128 matrix and `nvec` 128-vectors from L2 into LDS, split into an
+// early load (registers) and a late store so the L2/MALL latency hides under the projections' MFMAs
+struct StageRegs {
+    float4 w[UNIT / 4 / THREADS];
+    float4 vec;
+};
+__device__ __forceinline__ StageRegs stage_load(const float* __restrict__ wimg, const float* __restrict__ vecs,
+                                                int nvec, int tid) {
+    StageRegs r;
     const float4* src = reinterpret_cast<const float4*>(wimg);
+#pragma unroll
+    for (int it = 0; it < UNIT / 4 / THREADS; ++it) r.w[it] = src[it * THREADS + tid];
+    r.vec = (tid < nvec * HID / 4) ? reinterpret_cast<const float4*>(vecs)[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return r;
+}
+__device__ __forceinline__ void stage_store(const Lds& v, const StageRegs& r, int nvec, int tid) {
     float4* dst = reinterpret_cast<float4*>(v.W);
 #pragma unroll
-    for (int it = 0; it < UNIT / 4 / THREADS; ++it) dst[it * THREADS + tid] = src[it * THREADS + tid];
-    if (tid < nvec * HID / 4)
-        reinterpret_cast<float4*>(v.vec)[tid] = reinterpret_cast<const float4*>(vecs)[tid];
+    for (int it = 0; it < UNIT / 4 / THREADS; ++it) dst[it * THREADS + tid] = r.w[it];
+    if (tid < nvec * HID / 4) reinterpret_cast<float4*>(v.vec)[tid] = r.vec;
 }
 
 // P[a][f] = b1'[f] + sum_k W1a'[f][k] H[a][k]  -> v.A ;  Q[a][f] = sum_k W1b'[f][k] H[a][k] -> v.B
-__device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, const float* __restrict__ unit_a,
-                                         const float* __restrict__ unit_b, const float* __restrict__ bias) {
+__device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, const BFrag& bf, float bias) {
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3;
-    const bool isP = w < 4;
-    const float* unit = (isP ? unit_a : unit_b) + nt * (UNIT / 4);
-    float* dst = isP ? v.A : v.B;
-    const float b = isP ? bias[32 * nt + c] : 0.0f;
+    float* dst = (w < 4) ? v.A : v.B;
     const int mtiles = nb > 32 ? 2 : 1;
     for (int mt = 0; mt < mtiles; ++mt) {
-        floatx16 acc = splat16(b);
+        floatx16 acc = splat16(bias);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128(acc, v.C, arow, hh, unit, lane);
+        gemm_k128(acc, v.C, arow, hh, bf);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
@@ -221,7 +255,9 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
         float m = 0.0f;
         if (valid) m = emask ? float(emask[v.idx[i] * N + v.idx[j]]) : 1.0f;
 
-        // ---- first edge layer, generated directly as MFMA A-fragments: lane = (pair c, k = 64*hh + s)
+        // ---- first edge layer, generated as MFMA A-fragments: lane = (pair c, k = 64*hh + s).  Kept as a
+        // separate VALU phase (sched_barrier) so the MFMA loop below is a dense matrix-pipe stream that one
+        // wave can keep saturated while the SIMD's other wave is in its VALU phases.
         float a[64];
         {
             const float4* Pp = reinterpret_cast<const float4*>(v.A + i * LDH + 64 * hh);
@@ -235,16 +271,27 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
                 a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
             }
         }
-        // ---- second edge layer: [32 pairs x 128] = A[32 x 128] * W2'^T, 4 feature tiles, exact fp32 MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- second edge layer: [32 pairs x 128] = A[32 x 128] * W2'^T, 4 feature tiles, exact fp32 MFMA;
+        // B fragments (one ds_read_b128 per k-step) run two steps ahead of their MFMAs
         floatx16 acc0 = splat16(bias[0]), acc1 = splat16(bias[1]), acc2 = splat16(bias[2]), acc3 = splat16(bias[3]);
+        {
+            float4 b0 = Wp[0], b1 = Wp[32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
-        for (int s = 0; s < 64; ++s) {
-            const float4 b = Wp[s * 32];
-            acc0 = mfma32(a[s], b.x, acc0);
-            acc1 = mfma32(a[s], b.y, acc1);
-            acc2 = mfma32(a[s], b.z, acc2);
-            acc3 = mfma32(a[s], b.w, acc3);
+            for (int s = 0; s < 64; ++s) {
+                float4 b2 = b1;
+                if (s + 2 < 64) b2 = Wp[(s + 2) * 32];
+                acc0 = mfma32(a[s], b0.x, acc0);
+                acc1 = mfma32(a[s], b0.y, acc1);
+                acc2 = mfma32(a[s], b0.z, acc2);
+                acc3 = mfma32(a[s], b0.w, acc3);
+                b0 = b1; b1 = b2;
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read_b128 of step s+2 ...
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... ahead of the 4 MFMAs of step s
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
         if (!EQUIV) {
             float mr[16];
@@ -360,40 +407,53 @@ __device__ __forceinline__ void spill_reduce(const Lds& v, int tid, bool equiv) 
 
 // GCL (egnn.py:45-80) on the LDS-resident molecule; `hown` is this wave's 32x32 tile of h in registers.
 __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ g,
-                                         floatx16& hown, const int8_t* __restrict__ emask, int N) {
+                                         floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3, mt = w >> 2;
     const float* vecs = g + G_VEC;
-    stage_edge_weights(v, g + G_W2, vecs + HID, 3, tid);
-    node_pre(v, nb, w, lane, g + G_W1A, g + G_W1B, vecs);
+    prof_event(pf, w, lane, 10);
+    {
+        // first-layer projections P,Q; the 64 KB W2' image streams from L2 underneath them
+        const StageRegs st = stage_load(g + G_W2, vecs + HID, 3, tid);
+        const BFrag bf = load_bfrag(g + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
+        node_pre(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
+        stage_store(v, st, 3, tid);
+    }
+    prof_event(pf, w, lane, 11);
     __syncthreads();                       // P, Q, W2', vectors in place; every read of H (v.C) done
     for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
     __syncthreads();
+    prof_event(pf, w, lane, 12);
     const Spill sp = edge_phase<false>(v, nb, w, lane, emask, N, 0.0f);
+    prof_event(pf, w, lane, 13);
+    const bool active = (mt == 0) || (nb > 32);
     __syncthreads();                       // every wave left the edge phase: P (v.A), Q (v.B) dead
     spill_publish(v, sp, w, lane, false);
     __syncthreads();
     spill_reduce(v, tid, false);
     __syncthreads();                       // aggregate complete in v.C
-    const bool active = (mt == 0) || (nb > 32);
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * mt + acc_row(reg, hh);
         if (row < nb) v.A[row * LDH + 32 * nt + c] = hown[reg];
     }
     __syncthreads();
+    prof_event(pf, w, lane, 14);
     // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
     if (active) {
+        const BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
+        const BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
         floatx16 acc = splat16(vecs[4 * HID + 32 * nt + c]);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128(acc, v.A, arow, hh, g + G_W3A + nt * (UNIT / 4), lane);
-        gemm_k128(acc, v.C, arow, hh, g + G_W3B + nt * (UNIT / 4), lane);
+        gemm_k128(acc, v.A, arow, hh, b3a);
+        gemm_k128(acc, v.C, arow, hh, b3b);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             if (row < nb) v.B[row * LDH + 32 * nt + c] = silu_u(acc[reg]);
         }
     }
+    prof_event(pf, w, lane, 15);
     __syncthreads();
     // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
     if (active) {
@@ -402,7 +462,8 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) acc[reg] = hown[reg] + b4;
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128(acc, v.B, arow, hh, g + G_W4 + nt * (UNIT / 4), lane);
+        const BFrag b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
+        gemm_k128(acc, v.B, arow, hh, b4f);
         hown = acc;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -410,24 +471,36 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
             if (row < nb) v.C[row * LDH + 32 * nt + c] = acc[reg];
         }
     }
+    prof_event(pf, w, lane, 16);
     __syncthreads();
 }
 
 // EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
 __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ e,
-                                           const int8_t* __restrict__ emask, int N, float norm_constant) {
+                                           const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf) {
+    const int c = lane & 31;
+    const int nt = w & 3;
     const float* vecs = e + E_VEC;
-    stage_edge_weights(v, e + E_W6, vecs + HID, 4, tid);
-    node_pre(v, nb, w, lane, e + E_W5A, e + E_W5B, vecs);
+    prof_event(pf, w, lane, 30);
+    {
+        const StageRegs st = stage_load(e + E_W6, vecs + HID, 4, tid);
+        const BFrag bf = load_bfrag(e + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
+        node_pre(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
+        stage_store(v, st, 4, tid);
+    }
     if (tid < 4 * nb) v.aggx[tid] = 0.0f;
+    prof_event(pf, w, lane, 31);
     __syncthreads();
+    prof_event(pf, w, lane, 32);
     const Spill sp = edge_phase<true>(v, nb, w, lane, emask, N, norm_constant);
+    prof_event(pf, w, lane, 33);
     __syncthreads();
     spill_publish(v, sp, w, lane, true);
     __syncthreads();
     spill_reduce(v, tid, true);
     __syncthreads();
     if (tid < 4 * nb && (tid & 3) < 3) v.xs[tid] += v.aggx[tid] * v.lm[tid >> 2];
+    prof_event(pf, w, lane, 34);
     __syncthreads();
 }
 
@@ -435,11 +508,12 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w,
 // writes eps_hat[a][0:3+nf] into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
 __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, const ModelDims& md,
                                                  const float* __restrict__ wp, float tfeat,
-                                                 const int8_t* __restrict__ emask, int N) {
+                                                 const int8_t* __restrict__ emask, int N, Prof& pf) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3, mt = w >> 2;
+    prof_event(pf, w, lane, 1);
 
     // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
     if (tid < 4 * nb) {
@@ -479,13 +553,15 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
         const int row = 32 * mt + acc_row(reg, hh);
         hown[reg] = (row < nb) ? v.C[row * LDH + 32 * nt + c] : 0.0f;
     }
+    prof_event(pf, w, lane, 2);
 
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) gcl_pass(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N);
-        equiv_pass(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant);
+        for (int gi = 0; gi < 2; ++gi) gcl_pass(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf);
+        equiv_pass(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf);
     }
+    prof_event(pf, w, lane, 3);
 
     // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
     float* eps = v.A;
@@ -511,6 +587,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     }
     if (nanbits) atomicOr(&v.misc[1], nanbits);
     __syncthreads();
+    prof_event(pf, w, lane, 4);
 }
 
 // compact the real atoms of molecule b: v.idx[0..n_b) = padded positions with node_mask != 0
@@ -547,6 +624,7 @@ struct FwdArgs {
     const float* context;
     float* out;
     int* nan_flags;
+    unsigned long long* prof;
 };
 
 __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
@@ -584,7 +662,10 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     __syncthreads();
     const float tfeat = p.t[size_t(b) * p.t_stride];
     const int8_t* em = p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr;
-    forward_molecule(v, nb, tid, p.md, p.wpack, tfeat, em, N);
+    Prof pf;
+    pf.buf = (b == 0) ? p.prof : nullptr;
+    pf.n = 0;
+    forward_molecule(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf);
     for (int e = tid; e < nb * D; e += THREADS) {
         const int a = e / D, d = e - a * D;
         out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
@@ -599,6 +680,7 @@ struct ChainArgs {
     const float* wpack;
     ModelDims md;
     dl_chain_args a;
+    unsigned long long* prof;
 };
 
 __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
@@ -646,7 +728,10 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         dl_step_coef cf;
         if (decode) { cf.t = 0.0f; cf.alpha_ts = 1.0f; cf.c_eps = 0.0f; cf.sigma = 0.0f; }
         else cf = g.coefs[q];
-        forward_molecule(v, nb, tid, p.md, p.wpack, cf.t, em, N);
+        Prof pf;
+        pf.buf = (b == 0 && q == 0) ? p.prof : nullptr;
+        pf.n = 0;
+        forward_molecule(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf);
         if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
             if (tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
             return;
@@ -719,6 +804,7 @@ __global__ void sampler_step_kernel(int total, int D, const float* __restrict__ 
 // Host side: weight packing and the C ABI
 // ---------------------------------------------------------------------------------------------------
 thread_local int g_last_hip = 0;
+unsigned long long* g_prof_buf = nullptr;   // diagnostics only (dl_set_profile_buffer)
 
 inline bool hip_ok(hipError_t e) {
     if (e != hipSuccess) { g_last_hip = int(e); return false; }
@@ -760,6 +846,8 @@ struct dl_model {
 extern "C" {
 
 int32_t dl_abi_version(void) { return DL_ABI_VERSION; }
+int32_t dl_profile_max_events(void) { return PROF_MAX_EVENTS; }
+void dl_set_profile_buffer(void* device_buf) { g_prof_buf = static_cast<unsigned long long*>(device_buf); }
 int32_t dl_last_hip_error(void) { return g_last_hip; }
 int32_t dl_max_atoms(void) { return NMAX; }
 
@@ -905,7 +993,7 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float*
     FwdArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
     a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
-    a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags;
+    a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags; a.prof = g_prof_buf;
     hipLaunchKernelGGL(egnn_forward_fc_kernel, dim3(B), dim3(THREADS), LDS_BYTES,
                        static_cast<hipStream_t>(stream), a);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
@@ -919,7 +1007,7 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T) return DL_ERR_BAD_ARG;
     if (g->B == 0) return DL_OK;
     ChainArgs a;
-    a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g;
+    a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
     hipLaunchKernelGGL(sample_chain_fc_kernel, dim3(g->B), dim3(THREADS), LDS_BYTES,
                        static_cast<hipStream_t>(stream), a);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;

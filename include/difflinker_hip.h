@@ -138,6 +138,11 @@ typedef struct dl_chain_args {
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
 
+/* Diagnostics: when set (device uint64 [8 waves][dl_profile_max_events()][2], or NULL to disable), the
+ * first workgroup of the next launches logs (phase tag, shader clock) pairs of its first forward. */
+void dl_set_profile_buffer(void* device_buf);
+int32_t dl_profile_max_events(void);
+
 const char* dl_error_string(int32_t status);
 int32_t dl_last_hip_error(void);
 int32_t dl_abi_version(void);

@@ -1,0 +1,72 @@
+"""Diagnostics: per-phase shader-clock timeline of one Dynamics.forward (workgroup 0), using the
+dl_set_profile_buffer hook.  Run on the GPU box:  python scripts/phase_timeline.py [--n 50] [--batch 256]"""
+import argparse
+import collections
+import ctypes
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--n', type=int, default=50)
+ap.add_argument('--batch', type=int, default=256)
+ap.add_argument('--layers', type=int, default=6)
+a = ap.parse_args()
+
+import __graft_entry__ as entry
+entry.build()
+from difflinker_amd import Dynamics, synthetic, _lib
+
+dev = torch.device('cuda:0')
+lib = _lib.load()
+mols = synthetic.fc_molecules(a.batch, a.n, a.n, (3, 12), 9, seed=1, uniform_size=True)
+from difflinker_amd.datasets import collate
+inp = synthetic.sampler_inputs(collate(mols))
+inp = {k: v.to(dev) for k, v in inp.items()}
+torch.manual_seed(0)
+dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=a.layers, norm_constant=1e-6).to(dev)
+B, N = inp['x'].shape[:2]
+z = torch.cat([inp['x'], inp['h']], 2) * inp['fragment_mask'] + torch.randn(B, N, 12, device=dev) * inp['linker_mask']
+t = torch.full((B, 1), 0.5, device=dev)
+args = dict(t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'],
+            context=inp['context'])
+for _ in range(3):
+    dyn.forward(**args)
+torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ev0.record()
+for _ in range(5):
+    dyn.forward(**args)
+ev1.record()
+torch.cuda.synchronize()
+print(f'forward (B={B}, n={a.n}, L={a.layers}): {ev0.elapsed_time(ev1) / 5:.3f} ms')
+
+maxev = lib.dl_profile_max_events()
+buf = torch.zeros((8, maxev, 2), dtype=torch.int64, device=dev)
+lib.dl_set_profile_buffer(ctypes.c_void_p(buf.data_ptr()))
+dyn.forward(**args)
+torch.cuda.synchronize()
+lib.dl_set_profile_buffer(None)
+ev = buf.cpu()
+names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: barrier+zero agg', (12, 13): 'gcl: EDGE tiles',
+         (13, 14): 'gcl: barriers+spill+h->lds', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
+         (16, 10): 'gcl: end barrier', (16, 30): 'gcl: end barrier', (30, 31): 'eq: stage+proj', (31, 32): 'eq: barrier',
+         (32, 33): 'eq: EDGE tiles', (33, 34): 'eq: barriers+spill+x', (34, 10): 'eq: end barrier', (34, 3): 'eq: end barrier',
+         (2, 10): 'h->regs', (3, 4): 'output head'}
+for w in range(8):
+    e = ev[w]
+    n = int((e[:, 0] != 0).sum())
+    tot = collections.OrderedDict()
+    for k in range(n - 1):
+        key = (int(e[k, 0]), int(e[k + 1, 0]))
+        nm = names.get(key, str(key))
+        tot[nm] = tot.get(nm, 0) + int(e[k + 1, 1] - e[k, 1])
+    total = int(e[n - 1, 1] - e[0, 1])
+    if w in (0, 3, 7):
+        print(f'--- wave {w}: {n} events, total {total} ticks')
+        for nm, v in tot.items():
+            print(f'   {nm:32s} {v:10d}  {100.0 * v / total:5.1f}%')
