@@ -10,9 +10,12 @@ import os
 import torch  # noqa: F401  (loads PyTorch-ROCm's libamdhip64 first so both share one HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdifflinker_hip.so')
+# DIFFLINKER_HIP_LIB: load another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get('DIFFLINKER_HIP_LIB') or os.path.join(_HERE, 'libdifflinker_hip.so')
 
 DL_OK = 0
+ABI_VERSION = 2
+PRECISIONS = {'fp32': 0, 'bf16x3': 1}
 DL_ERR_TOO_MANY_ATOMS = -3
 
 
@@ -21,7 +24,7 @@ class DLConfig(ctypes.Structure):
         ('n_dims', ctypes.c_int32), ('in_node_nf', ctypes.c_int32), ('context_node_nf', ctypes.c_int32),
         ('hidden_nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('inv_sublayers', ctypes.c_int32),
         ('condition_time', ctypes.c_int32), ('norm_constant', ctypes.c_float),
-        ('normalization_factor', ctypes.c_float),
+        ('normalization_factor', ctypes.c_float), ('precision', ctypes.c_int32),
     ]
 
 

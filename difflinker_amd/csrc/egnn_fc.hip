@@ -42,6 +42,10 @@ constexpr int DMAX = 16;            // row stride of the per-atom state z = [x(3
 constexpr int CTXMAX = 4;
 constexpr int THREADS = 512;
 constexpr int NWAVES = 8;
+#ifndef DL_STAGGER
+#define DL_STAGGER 127
+#endif
+constexpr int STAGGER = DL_STAGGER;     // s_sleep units (64 cycles) the upper half-workgroup waits before its first MFMA loop
 
 // ---- packed weight buffer (floats); mirrored by pack_model() below -------------------------------
 constexpr int OFF_EMB_W = 0;                          // [128][FINP]
@@ -134,6 +138,36 @@ __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- bf16x3 path: fp32 operands are split a = hi + lo (both bf16, round-to-nearest-even) and a product
+// a*w is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32
+// accumulate); the dropped lo*lo' term and the split residue are ~2^-17 relative.  Unlike the f32-input
+// MFMA (which runs at the fp32 VECTOR rate and did not overlap with this kernel's VALU work) the bf16 MFMA
+// is 16x faster, so the edge pass becomes VALU-bound (SiLU + the splits).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {      // v_cvt_pk_bf16_f32 (RNE)
+    bf16x2 p = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
+
+// 8 consecutive-k fp32 values -> MFMA fragments (8 bf16 = 4 VGPRs) of the hi and lo parts
+__device__ __forceinline__ void split8(const float (&u)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        h[q] = pack_bf16x2(u[2 * q], u[2 * q + 1]);
+        const float h0 = __uint_as_float(h[q] << 16), h1 = __uint_as_float(h[q] & 0xffff0000u);
+        l[q] = pack_bf16x2(u[2 * q] - h0, u[2 * q + 1] - h1);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__device__ __forceinline__ floatx16 mfma_bf(const uint4& a, const uint4& b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
@@ -149,17 +183,35 @@ __device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, i
     return b;
 }
 
-// acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.
-// A: LDS row `arow` of a [n][LDH] tile; this lane supplies k = 64*hh + s.  B: pre-loaded fragments.
+// acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.  B: pre-loaded fragments.
+// PREC 0 (fp32 MFMA): A = LDS row `arow`, this lane supplies k = 64*hh + s.
+// PREC 1 (bf16x3):    this lane supplies k = 16*slab + 8*hh + e; b.q[slab] / b.q[8+slab] = hi / lo parts.
+template <int PREC>
 __device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh, const BFrag& b) {
-    const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
+    if constexpr (PREC == 0) {
+        const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
 #pragma unroll
-    for (int sg = 0; sg < 16; ++sg) {
-        const float4 a = ap[sg];
-        acc = mfma32(a.x, b.q[sg].x, acc);
-        acc = mfma32(a.y, b.q[sg].y, acc);
-        acc = mfma32(a.z, b.q[sg].z, acc);
-        acc = mfma32(a.w, b.q[sg].w, acc);
+        for (int sg = 0; sg < 16; ++sg) {
+            const float4 a = ap[sg];
+            acc = mfma32(a.x, b.q[sg].x, acc);
+            acc = mfma32(a.y, b.q[sg].y, acc);
+            acc = mfma32(a.z, b.q[sg].z, acc);
+            acc = mfma32(a.w, b.q[sg].w, acc);
+        }
+    } else {
+        const float* ap = abuf + arow * LDH + 8 * hh;
+#pragma unroll
+        for (int slab = 0; slab < 8; ++slab) {
+            const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * slab);
+            const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * slab + 4);
+            const float u[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            uint4 hi, lo;
+            split8(u, hi, lo);
+            const uint4 bh = __builtin_bit_cast(uint4, b.q[slab]), bl = __builtin_bit_cast(uint4, b.q[8 + slab]);
+            acc = mfma_bf(hi, bh, acc);
+            acc = mfma_bf(hi, bl, acc);
+            acc = mfma_bf(lo, bh, acc);
+        }
     }
 }
 
@@ -186,6 +238,7 @@ __device__ __forceinline__ void stage_store(const Lds& v, const StageRegs& r, in
 }
 
 // P[a][f] = b1'[f] + sum_k W1a'[f][k] H[a][k]  -> v.A ;  Q[a][f] = sum_k W1b'[f][k] H[a][k] -> v.B
+template <int PREC>
 __device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, const BFrag& bf, float bias) {
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3;
@@ -194,7 +247,7 @@ __device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, 
     for (int mt = 0; mt < mtiles; ++mt) {
         floatx16 acc = splat16(bias);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128(acc, v.C, arow, hh, bf);
+        gemm_k128<PREC>(acc, v.C, arow, hh, bf);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
@@ -216,7 +269,7 @@ struct Spill {
     float v[4];
 };
 
-template <bool EQUIV>
+template <bool EQUIV, int PREC>
 __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask,
                                             int N, float norm_constant) {
     const int c = lane & 31, hh = lane >> 5;
@@ -236,6 +289,15 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
     const float4* wdp = reinterpret_cast<const float4*>(v.vec + HID + 64 * hh);
     const float4* Wp = reinterpret_cast<const float4*>(v.W) + (64 * hh * 32 + c);
 
+    // The two waves that share a SIMD (w, w+4) start every phase in lockstep: both in their VALU
+    // phase (matrix pipe idle), then both in their MFMA loop (pipe shared fairly) - they overlap
+    // nothing, and the pipe idles for one VALU phase per tile.  Holding the upper wave back by about
+    // one VALU phase ONCE puts the pair into the complementary rhythm (one wave's VALU phase under
+    // the other's solo MFMA time), which then sustains itself.
+    if (STAGGER > 0 && w >= NWAVES / 2) {
+        if (STAGGER > 127) __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(STAGGER > 127 ? STAGGER - 127 : STAGGER);
+    }
     for (int t = t_begin; t < t_end; ++t) {
         const int p = 32 * t + c;
         const bool valid = p < npairs;
@@ -255,43 +317,88 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
         float m = 0.0f;
         if (valid) m = emask ? float(emask[v.idx[i] * N + v.idx[j]]) : 1.0f;
 
-        // ---- first edge layer, generated as MFMA A-fragments: lane = (pair c, k = 64*hh + s).  Kept as a
-        // separate VALU phase (sched_barrier) so the MFMA loop below is a dense matrix-pipe stream that one
-        // wave can keep saturated while the SIMD's other wave is in its VALU phases.
-        float a[64];
-        {
-            const float4* Pp = reinterpret_cast<const float4*>(v.A + i * LDH + 64 * hh);
-            const float4* Qp = reinterpret_cast<const float4*>(v.B + j * LDH + 64 * hh);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
-                a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
-                a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
-                a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
-                a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- second edge layer: [32 pairs x 128] = A[32 x 128] * W2'^T, 4 feature tiles, exact fp32 MFMA;
-        // B fragments (one ds_read_b128 per k-step) run two steps ahead of their MFMAs
         floatx16 acc0 = splat16(bias[0]), acc1 = splat16(bias[1]), acc2 = splat16(bias[2]), acc3 = splat16(bias[3]);
-        {
-            float4 b0 = Wp[0], b1 = Wp[32];
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        if constexpr (PREC == 0) {
+            // ---- first edge layer, generated as MFMA A-fragments: lane = (pair c, k = 64*hh + s).  Kept as a
+            // separate VALU phase (sched_barrier) so the MFMA loop below is a dense matrix-pipe stream that one
+            // wave can keep saturated while the SIMD's other wave is in its VALU phases.
+            float a[64];
+            {
+                const float4* Pp = reinterpret_cast<const float4*>(v.A + i * LDH + 64 * hh);
+                const float4* Qp = reinterpret_cast<const float4*>(v.B + j * LDH + 64 * hh);
+    #pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
+                    a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
+                    a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
+                    a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
+                    a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- second edge layer: [32 pairs x 128] = A[32 x 128] * W2'^T, 4 feature tiles, exact fp32 MFMA;
+            // B fragments (one ds_read_b128 per k-step) run two steps ahead of their MFMAs
+            {
+                float4 b0 = Wp[0], b1 = Wp[32];
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    #pragma unroll
+                for (int s = 0; s < 64; ++s) {
+                    float4 b2 = b1;
+                    if (s + 2 < 64) b2 = Wp[(s + 2) * 32];
+                    acc0 = mfma32(a[s], b0.x, acc0);
+                    acc1 = mfma32(a[s], b0.y, acc1);
+                    acc2 = mfma32(a[s], b0.z, acc2);
+                    acc3 = mfma32(a[s], b0.w, acc3);
+                    b0 = b1; b1 = b2;
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read_b128 of step s+2 ...
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... ahead of the 4 MFMAs of step s
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // ---- first edge layer as bf16 hi/lo A-fragments: lane = (pair c, k = 16*slab + 8*hh + e)
+            uint4 ah[8], al[8];
+            {
+                const float* Pp = v.A + i * LDH + 8 * hh;
+                const float* Qp = v.B + j * LDH + 8 * hh;
+                const float* wrb = v.vec + 8 * hh;
+                const float* wdb = v.vec + HID + 8 * hh;
 #pragma unroll
-            for (int s = 0; s < 64; ++s) {
-                float4 b2 = b1;
-                if (s + 2 < 64) b2 = Wp[(s + 2) * 32];
-                acc0 = mfma32(a[s], b0.x, acc0);
-                acc1 = mfma32(a[s], b0.y, acc1);
-                acc2 = mfma32(a[s], b0.z, acc2);
-                acc3 = mfma32(a[s], b0.w, acc3);
-                b0 = b1; b1 = b2;
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read_b128 of step s+2 ...
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... ahead of the 4 MFMAs of step s
+                for (int slab = 0; slab < 8; ++slab) {
+                    float u[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int k0 = 16 * slab + 4 * q;
+                        const float4 P = *reinterpret_cast<const float4*>(Pp + k0);
+                        const float4 Q = *reinterpret_cast<const float4*>(Qp + k0);
+                        const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
+                        const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
+                        u[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
+                        u[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
+                        u[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
+                        u[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+                    }
+                    split8(u, ah[slab], al[slab]);
+                }
+            }
+            // ---- second edge layer on the bf16 matrix pipe: per 16-k slab, 4 feature tiles x 3 split terms
+            const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane;
+#pragma unroll
+            for (int slab = 0; slab < 8; ++slab) {
+                uint4 bh[4], bl[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bh[nt] = Wq[(slab * 4 + nt) * 64];
+                    bl[nt] = Wq[((8 + slab) * 4 + nt) * 64];
+                }
+                acc0 = mfma_bf(ah[slab], bh[0], acc0); acc1 = mfma_bf(ah[slab], bh[1], acc1);
+                acc2 = mfma_bf(ah[slab], bh[2], acc2); acc3 = mfma_bf(ah[slab], bh[3], acc3);
+                acc0 = mfma_bf(ah[slab], bl[0], acc0); acc1 = mfma_bf(ah[slab], bl[1], acc1);
+                acc2 = mfma_bf(ah[slab], bl[2], acc2); acc3 = mfma_bf(ah[slab], bl[3], acc3);
+                acc0 = mfma_bf(al[slab], bh[0], acc0); acc1 = mfma_bf(al[slab], bh[1], acc1);
+                acc2 = mfma_bf(al[slab], bh[2], acc2); acc3 = mfma_bf(al[slab], bh[3], acc3);
             }
         }
-        __builtin_amdgcn_sched_barrier(0);
         // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
         if (!EQUIV) {
             float mr[16];
@@ -406,6 +513,7 @@ __device__ __forceinline__ void spill_reduce(const Lds& v, int tid, bool equiv) 
 }
 
 // GCL (egnn.py:45-80) on the LDS-resident molecule; `hown` is this wave's 32x32 tile of h in registers.
+template <int PREC>
 __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ g,
                                          floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
@@ -416,7 +524,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         // first-layer projections P,Q; the 64 KB W2' image streams from L2 underneath them
         const StageRegs st = stage_load(g + G_W2, vecs + HID, 3, tid);
         const BFrag bf = load_bfrag(g + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
-        node_pre(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
+        node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
         stage_store(v, st, 3, tid);
     }
     prof_event(pf, w, lane, 11);
@@ -424,7 +532,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
     for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
     __syncthreads();
     prof_event(pf, w, lane, 12);
-    const Spill sp = edge_phase<false>(v, nb, w, lane, emask, N, 0.0f);
+    const Spill sp = edge_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f);
     prof_event(pf, w, lane, 13);
     const bool active = (mt == 0) || (nb > 32);
     __syncthreads();                       // every wave left the edge phase: P (v.A), Q (v.B) dead
@@ -445,8 +553,8 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         const BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
         floatx16 acc = splat16(vecs[4 * HID + 32 * nt + c]);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128(acc, v.A, arow, hh, b3a);
-        gemm_k128(acc, v.C, arow, hh, b3b);
+        gemm_k128<PREC>(acc, v.A, arow, hh, b3a);
+        gemm_k128<PREC>(acc, v.C, arow, hh, b3b);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
@@ -463,7 +571,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         for (int reg = 0; reg < 16; ++reg) acc[reg] = hown[reg] + b4;
         const int arow = min(32 * mt + c, nb - 1);
         const BFrag b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
-        gemm_k128(acc, v.B, arow, hh, b4f);
+        gemm_k128<PREC>(acc, v.B, arow, hh, b4f);
         hown = acc;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -476,6 +584,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
 }
 
 // EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
+template <int PREC>
 __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ e,
                                            const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf) {
     const int c = lane & 31;
@@ -485,14 +594,14 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w,
     {
         const StageRegs st = stage_load(e + E_W6, vecs + HID, 4, tid);
         const BFrag bf = load_bfrag(e + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
-        node_pre(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
+        node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
         stage_store(v, st, 4, tid);
     }
     if (tid < 4 * nb) v.aggx[tid] = 0.0f;
     prof_event(pf, w, lane, 31);
     __syncthreads();
     prof_event(pf, w, lane, 32);
-    const Spill sp = edge_phase<true>(v, nb, w, lane, emask, N, norm_constant);
+    const Spill sp = edge_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant);
     prof_event(pf, w, lane, 33);
     __syncthreads();
     spill_publish(v, sp, w, lane, true);
@@ -506,6 +615,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w,
 
 // Dynamics.forward for the molecule resident in LDS: reads v.z (state), v.ctx, v.lm, time feature t;
 // writes eps_hat[a][0:3+nf] into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
+template <int PREC>
 __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, const ModelDims& md,
                                                  const float* __restrict__ wp, float tfeat,
                                                  const int8_t* __restrict__ emask, int N, Prof& pf) {
@@ -558,8 +668,8 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) gcl_pass(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf);
-        equiv_pass(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf);
+        for (int gi = 0; gi < 2; ++gi) gcl_pass<PREC>(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf);
+        equiv_pass<PREC>(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf);
     }
     prof_event(pf, w, lane, 3);
 
@@ -627,6 +737,7 @@ struct FwdArgs {
     unsigned long long* prof;
 };
 
+template <int PREC>
 __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const Lds v = lds_view(lds_raw);
@@ -665,7 +776,7 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     Prof pf;
     pf.buf = (b == 0) ? p.prof : nullptr;
     pf.n = 0;
-    forward_molecule(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf);
+    forward_molecule<PREC>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf);
     for (int e = tid; e < nb * D; e += THREADS) {
         const int a = e / D, d = e - a * D;
         out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
@@ -683,6 +794,7 @@ struct ChainArgs {
     unsigned long long* prof;
 };
 
+template <int PREC>
 __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     const Lds v = lds_view(lds_raw);
@@ -731,7 +843,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         Prof pf;
         pf.buf = (b == 0 && q == 0) ? p.prof : nullptr;
         pf.n = 0;
-        forward_molecule(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf);
+        forward_molecule<PREC>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf);
         if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
             if (tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
             return;
@@ -831,6 +943,59 @@ void pack_lds_image(float* dst, const float* w, int ld, double scale) {
                 dst[(k * 32 + c) * 4 + nt] = float(double(w[size_t(32 * nt + c) * ld + k]) * scale);
 }
 
+inline uint16_t bf16_rne(float x) {                       // round-to-nearest-even fp32 -> bf16 bits
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40);   // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return uint16_t(u >> 16);
+}
+inline float bf16_to_float(uint16_t h) {
+    uint32_t u = uint32_t(h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// hi/lo bf16 parts of scale*W[f][k]
+inline void split_bf16(double v, uint16_t& hi, uint16_t& lo) {
+    const float x = float(v);
+    hi = bf16_rne(x);
+    lo = bf16_rne(x - bf16_to_float(hi));
+}
+
+// bf16x3 node-fragment order: unit[nt][part*8 + slab][lane][e] (bf16), value = part(W[f = 32nt + (lane&31)][k]),
+// k = 16*slab + 8*(lane>>5) + e; same bytes as the fp32 unit (64 KB), read as 16 x dwordx4 per lane
+void pack_unit_bf16(float* dstf, const float* w, int ld, int col0, double scale) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
+    for (int nt = 0; nt < 4; ++nt)
+        for (int slab = 0; slab < 8; ++slab)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 32 * nt + (lane & 31);
+                    const int k = 16 * slab + 8 * (lane >> 5) + e;
+                    uint16_t hi, lo;
+                    split_bf16(double(w[size_t(f) * ld + col0 + k]) * scale, hi, lo);
+                    dst[(((nt * 16 + slab) * 64 + lane) * 8) + e] = hi;
+                    dst[(((nt * 16 + 8 + slab) * 64 + lane) * 8) + e] = lo;
+                }
+}
+
+// bf16x3 LDS image: img[part*8 + slab][nt][lane][e]
+void pack_lds_image_bf16(float* dstf, const float* w, int ld, double scale) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
+    for (int slab = 0; slab < 8; ++slab)
+        for (int nt = 0; nt < 4; ++nt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 32 * nt + (lane & 31);
+                    const int k = 16 * slab + 8 * (lane >> 5) + e;
+                    uint16_t hi, lo;
+                    split_bf16(double(w[size_t(f) * ld + k]) * scale, hi, lo);
+                    dst[(((slab * 4 + nt) * 64 + lane) * 8) + e] = hi;
+                    dst[((((8 + slab) * 4 + nt) * 64 + lane) * 8) + e] = lo;
+                }
+}
+
 void pack_vec(float* dst, const float* src, int stride, double scale) {
     for (int f = 0; f < HID; ++f) dst[f] = float(double(src[size_t(f) * stride]) * scale);
 }
@@ -872,6 +1037,7 @@ static int32_t check_cfg(const dl_config* c) {
     if (c->in_node_nf + 1 + c->context_node_nf > FINP) return DL_ERR_UNSUPPORTED;
     if (c->n_layers < 1 || c->n_layers > 64) return DL_ERR_UNSUPPORTED;
     if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
+    if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_BF16X3) return DL_ERR_UNSUPPORTED;
     return DL_OK;
 }
 
@@ -890,6 +1056,13 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     const size_t total = size_t(OFF_BLOCKS) + size_t(L) * BLOCK_SIZE;
     float* hp = static_cast<float*>(calloc(total, sizeof(float)));
     if (!hp) return DL_ERR_ALLOC;
+    const bool bf = cfg->precision == DL_PRECISION_BF16X3;
+    auto unit = [&](float* d, const float* ww, int ld, int col0, double sc) {
+        if (bf) pack_unit_bf16(d, ww, ld, col0, sc); else pack_unit(d, ww, ld, col0, sc);
+    };
+    auto image = [&](float* d, const float* ww, int ld, double sc) {
+        if (bf) pack_lds_image_bf16(d, ww, ld, sc); else pack_lds_image(d, ww, ld, sc);
+    };
     const double c = -1.4426950408889634;            // -log2(e): y = c * pre-activation
     const double inv_norm = 1.0 / double(cfg->normalization_factor);
     int ti = 0;
@@ -913,12 +1086,12 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             const float* w3 = w[ti++]; const float* b3 = w[ti++];     // node_mlp.0 [128][256]
             const float* w4 = w[ti++]; const float* b4 = w[ti++];     // node_mlp.2 [128][128]
             const int ld1 = 2 * HID + 2;
-            pack_unit(g + G_W1A, w1, ld1, 0, c);
-            pack_unit(g + G_W1B, w1, ld1, HID, c);
-            pack_unit(g + G_W3A, w3, 2 * HID, 0, c);
-            pack_unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);         // agg arrives as c*norm*true agg
-            pack_unit(g + G_W4, w4, HID, 0, 1.0 / c);
-            pack_lds_image(g + G_W2, w2, HID, 1.0);
+            unit(g + G_W1A, w1, ld1, 0, c);
+            unit(g + G_W1B, w1, ld1, HID, c);
+            unit(g + G_W3A, w3, 2 * HID, 0, c);
+            unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);         // agg arrives as c*norm*true agg
+            unit(g + G_W4, w4, HID, 0, 1.0 / c);
+            image(g + G_W2, w2, HID, 1.0);
             float* vv = g + G_VEC;
             pack_vec(vv + 0 * HID, b1, 1, c);
             pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);             // radial column
@@ -932,9 +1105,9 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         const float* w6 = w[ti++]; const float* b6 = w[ti++];         // coord_mlp.2 [128][128]
         const float* w7 = w[ti++];                                    // coord_mlp.4 [1][128], no bias
         const int ld5 = 2 * HID + 2;
-        pack_unit(e + E_W5A, w5, ld5, 0, c);
-        pack_unit(e + E_W5B, w5, ld5, HID, c);
-        pack_lds_image(e + E_W6, w6, HID, 1.0);
+        unit(e + E_W5A, w5, ld5, 0, c);
+        unit(e + E_W5B, w5, ld5, HID, c);
+        image(e + E_W6, w6, HID, 1.0);
         float* vv = e + E_VEC;
         pack_vec(vv + 0 * HID, b5, 1, c);
         pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
@@ -955,12 +1128,14 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     free(hp);
     static bool attr_done = false;
     if (!attr_done) {
-        if (!hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(egnn_forward_fc_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES))) ||
-            !hip_ok(hipFuncSetAttribute(reinterpret_cast<const void*>(sample_chain_fc_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)))) {
-            hipFree(m->d_pack); free(m); return DL_ERR_HIP;
-        }
+        const void* kernels[4] = {reinterpret_cast<const void*>(egnn_forward_fc_kernel<0>),
+                                  reinterpret_cast<const void*>(egnn_forward_fc_kernel<1>),
+                                  reinterpret_cast<const void*>(sample_chain_fc_kernel<0>),
+                                  reinterpret_cast<const void*>(sample_chain_fc_kernel<1>)};
+        for (const void* k : kernels)
+            if (!hip_ok(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)))) {
+                (void)hipFree(m->d_pack); free(m); return DL_ERR_HIP;
+            }
         attr_done = true;
     }
     *out = m;
@@ -969,7 +1144,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
 
 void dl_model_destroy(dl_model* m) {
     if (!m) return;
-    if (m->d_pack) hipFree(m->d_pack);
+    if (m->d_pack) (void)hipFree(m->d_pack);
     free(m);
 }
 
@@ -994,8 +1169,12 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float*
     a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
     a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
     a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags; a.prof = g_prof_buf;
-    hipLaunchKernelGGL(egnn_forward_fc_kernel, dim3(B), dim3(THREADS), LDS_BYTES,
-                       static_cast<hipStream_t>(stream), a);
+    if (m->cfg.precision == DL_PRECISION_BF16X3)
+        hipLaunchKernelGGL(egnn_forward_fc_kernel<1>, dim3(B), dim3(THREADS), LDS_BYTES,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(egnn_forward_fc_kernel<0>, dim3(B), dim3(THREADS), LDS_BYTES,
+                           static_cast<hipStream_t>(stream), a);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
 
@@ -1008,8 +1187,12 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if (g->B == 0) return DL_OK;
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
-    hipLaunchKernelGGL(sample_chain_fc_kernel, dim3(g->B), dim3(THREADS), LDS_BYTES,
-                       static_cast<hipStream_t>(stream), a);
+    if (m->cfg.precision == DL_PRECISION_BF16X3)
+        hipLaunchKernelGGL(sample_chain_fc_kernel<1>, dim3(g->B), dim3(THREADS), LDS_BYTES,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(sample_chain_fc_kernel<0>, dim3(g->B), dim3(THREADS), LDS_BYTES,
+                           static_cast<hipStream_t>(stream), a);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
 

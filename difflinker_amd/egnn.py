@@ -12,6 +12,7 @@ There is no PyTorch/CPU fallback: CPU tensors, a missing HIP library or hyper-pa
 the HIP path raise.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -174,10 +175,13 @@ class Dynamics(nn.Module):
         self.n_layers = n_layers
         self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
         self._hip_models = {}                          # device index -> (_HipModel, weight version)
+        # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'bf16x3' = split-bf16 on the
+        # matrix cores (default, ~3e-6 rel-L2 on a 500-step chain), 'fp32' = exact fp32 MFMA.
+        self.precision = os.environ.get('DIFFLINKER_PRECISION', 'bf16x3')
 
     # ---- packed weights -----------------------------------------------------------------------------
     def _weight_version(self):
-        return tuple(p._version for p in self.dynamics.parameters()) + \
+        return (self.precision,) + tuple(p._version for p in self.dynamics.parameters()) + \
             tuple(p.data_ptr() for p in self.dynamics.parameters())
 
     def invalidate_packed(self):
@@ -191,7 +195,8 @@ class Dynamics(nn.Module):
         return _lib.DLConfig(n_dims=self.n_dims, in_node_nf=self.in_node_nf, context_node_nf=self.context_node_nf,
                              hidden_nf=self.dynamics.hidden_nf, n_layers=self.n_layers, inv_sublayers=2,
                              condition_time=1, norm_constant=float(self.norm_constant),
-                             normalization_factor=float(self.normalization_factor))
+                             normalization_factor=float(self.normalization_factor),
+                             precision=_lib.PRECISIONS[self.precision])
 
     def hip_model(self, device):
         """``dl_model`` handle for ``device`` (packs + uploads the weights on first use / after a change)."""

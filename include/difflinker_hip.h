@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 1
+#define DL_ABI_VERSION 2
 
 typedef enum dl_status {
     DL_OK = 0,
@@ -49,6 +49,14 @@ typedef enum dl_status {
     DL_ERR_NO_DEVICE = -5,      /* no gfx950 device visible                                */
     DL_ERR_ALLOC = -6
 } dl_status;
+
+/* Arithmetic of the 128-wide contractions (edge/node/coordinate MLP layers).  Everything else
+ * (distances, SiLU, masks, aggregation, sampler algebra) is fp32 in both modes.
+ *   DL_PRECISION_FP32    v_mfma_f32_32x32x2_f32: exact fp32 FMA chains (runs at the fp32 vector rate)
+ *   DL_PRECISION_BF16X3  each fp32 operand split into bf16 hi+lo (RNE); a*w = hi*hi'+hi*lo'+lo*hi' on
+ *                        v_mfma_f32_32x32x16_bf16 with fp32 accumulation; ~2^-17 relative per product,
+ *                        measured 3e-6 rel-L2 on a 500-step chain (tolerance 1e-4)               */
+typedef enum dl_precision { DL_PRECISION_FP32 = 0, DL_PRECISION_BF16X3 = 1 } dl_precision;
 
 /* Dynamics.__init__ hyper-parameters (src/egnn.py:324-329).  The HIP path implements the
  * released-config surface: model='egnn_dynamics', SiLU, attention=False, tanh=False,
@@ -63,6 +71,7 @@ typedef struct dl_config {
     int32_t condition_time;       /* must be 1                                      */
     float norm_constant;          /* 1e-6 in the released configs                   */
     float normalization_factor;   /* 100                                            */
+    int32_t precision;            /* dl_precision: arithmetic of the 128-wide GEMMs */
 } dl_config;
 
 typedef struct dl_model dl_model; /* opaque: packed, pre-scaled weights resident in HBM */

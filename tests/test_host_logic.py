@@ -26,10 +26,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dl_abi_version() == 1
+    assert lib.dl_abi_version() == _lib.ABI_VERSION == 2
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
-    cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0)
+    cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
     assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == 4 + 6 * 21
 
 
