@@ -58,30 +58,42 @@ def build_model(cfg, device):
     return edm.to(device)
 
 
-def cpu_baseline(edm, cfg, inp, n_forwards):
-    """Oracle = PyTorch-CPU port of the reference path, all host cores, bounded sample."""
+def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
+    """Oracle = PyTorch-CPU port of the reference path on the host cores, bounded sample: the first
+    `sample_batch` molecules of the same batch, best of a few thread counts (PyTorch CPU ops stop scaling
+    well before a many-core host is full), scaled linearly to the whole batch and to T+1 forwards
+    (per-edge cost is constant; every step costs the same)."""
     from oracle import egnn_oracle
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     sd = {k: v.detach().cpu().clone() for k, v in edm.dynamics.state_dict().items()}
     ocfg = egnn_oracle.EGNNConfig(in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], n_layers=cfg['n_layers'])
     B, N = inp['x'].shape[:2]
+    b = min(sample_batch, B)
     g = torch.Generator().manual_seed(1)
     z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
         torch.randn((B, N, 3 + cfg['nf']), generator=g) * inp['linker_mask']
-    t = torch.full((B, 1), 0.5)
-    args = (sd, ocfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    t = torch.full((b, 1), 0.5)
+    em = inp['edge_mask'].view(B, N * N)[:b].reshape(-1, 1)
+    args = (sd, ocfg, t, z[:b], inp['node_mask'][:b], inp['linker_mask'][:b], em, inp['context'][:b])
+    best = None
     with torch.no_grad():
-        egnn_oracle.dynamics_forward(*args)                # warm-up (edge list, allocator)
-        t0 = time.perf_counter()
-        for _ in range(n_forwards):
-            egnn_oracle.dynamics_forward(*args)
-        dt = (time.perf_counter() - t0) / n_forwards
-    chain_s = dt * (cfg['T'] + 1)
-    return {'value': B / chain_s, 'unit': 'molecules/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_forwards} Dynamics.forward calls of the same batch (B={B}, N={N}, L={cfg["n_layers"]}) after 1 '
-                      f'warm-up, {dt:.2f} s each, extrapolated linearly to T+1={cfg["T"] + 1} forwards',
-            's_per_forward': dt}
+        for threads in sorted({min(8, cores), min(16, cores), min(32, cores), min(64, cores)}):
+            torch.set_num_threads(threads)
+            egnn_oracle.dynamics_forward(*args)            # warm-up (edge list, allocator)
+            t0 = time.perf_counter()
+            for _ in range(n_forwards):
+                egnn_oracle.dynamics_forward(*args)
+            dt = (time.perf_counter() - t0) / n_forwards
+            if best is None or dt < best[0]:
+                best = (dt, threads)
+    dt, threads = best
+    fwd_full = dt * B / b
+    chain_s = fwd_full * (cfg['T'] + 1)
+    return {'value': B / chain_s, 'unit': 'molecules/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_forwards} Dynamics.forward calls on the first {b} of the {B} molecules (N={N}, '
+                      f'L={cfg["n_layers"]}) after 1 warm-up, best of 8/16/32/64 threads ({threads}): {dt:.2f} s each; '
+                      f'scaled x{B / b:g} to the batch and x{cfg["T"] + 1} to the chain; host has {cores} logical cores',
+            's_per_forward_full_batch': fwd_full}
 
 
 def main():

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <cmath>
 
 #include "../../include/difflinker_hip.h"
 
@@ -56,11 +57,13 @@ constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
 // GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image), vectors
 constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT;
 constexpr int G_VEC = 6 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
-constexpr int GCL_SIZE = 6 * UNIT + 6 * HID;
+constexpr int G_SCALE = G_VEC + 6 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max
+constexpr int GCL_SIZE = 6 * UNIT + 6 * HID + 8;
 // equivariant update: units W5a', W5b', W6' (LDS image), vectors
 constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT;
 constexpr int E_VEC = 3 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
-constexpr int EQ_SIZE = 3 * UNIT + 5 * HID;
+constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max
+constexpr int EQ_SIZE = 3 * UNIT + 5 * HID + 8;
 constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
 
 // ---- LDS layout (floats) ---------------------------------------------------------------------------
@@ -78,7 +81,8 @@ constexpr int L_FRAG = L_LM + 56;                     // fragment mask [n]
 constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padded position [n] (int)
 constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
-constexpr int L_TOTAL = L_MISC + 16;
+constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
+constexpr int L_TOTAL = L_FMAX + 8;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -87,6 +91,7 @@ static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) 
 struct Lds {
     float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag, *ctx;
     int *idx, *misc;
+    unsigned* fmax;
 };
 
 __device__ __forceinline__ Lds lds_view(float* base) {
@@ -95,6 +100,7 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     v.xs = base + L_XS; v.x0 = base + L_X0; v.aggx = base + L_AGGX; v.z = base + L_Z;
     v.lm = base + L_LM; v.frag = base + L_FRAG; v.ctx = base + L_CTX;
     v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
+    v.fmax = reinterpret_cast<unsigned*>(base + L_FMAX);
     return v;
 }
 
@@ -138,34 +144,51 @@ __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// ---- bf16x3 path: fp32 operands are split a = hi + lo (both bf16, round-to-nearest-even) and a product
-// a*w is taken as hi*hi' + hi*lo' + lo*hi' on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, fp32
-// accumulate); the dropped lo*lo' term and the split residue are ~2^-17 relative.  Unlike the f32-input
-// MFMA (which runs at the fp32 VECTOR rate and did not overlap with this kernel's VALU work) the bf16 MFMA
-// is 16x faster, so the edge pass becomes VALU-bound (SiLU + the splits).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// ---- f16x3 path (PREC 1): every fp32 operand of a 128-wide contraction is scaled by a power of two into the
+// fp16 range and split x*s = hi + lo (both fp16); a product is taken as hi*hi' + hi*lo' + lo*hi' on the fp16
+// matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulate) and the accumulator is scaled back exactly.  The
+// split keeps ~21 significant bits per operand (error ~1e-6 per product, fp32-class: measured below the
+// fp32-vs-fp64 noise on a 100-step chain), unlike a bf16 split (16 bits).  Scales: static per weight matrix
+// (host, dl_model_create); dynamic per pass for the activations from a magnitude bound kept in LDS.
+// Unlike the f32-input MFMA - which runs at the fp32 VECTOR rate and did not overlap with this kernel's VALU
+// work - the fp16 MFMA is 16x faster, so the edge pass becomes VALU-bound (SiLU + the splits).
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {      // v_cvt_pk_bf16_f32 (RNE)
-    bf16x2 p = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(unsigned, p);
-}
-
-// 8 consecutive-k fp32 values -> MFMA fragments (8 bf16 = 4 VGPRs) of the hi and lo parts
+// 8 consecutive-k fp32 values (already scaled) -> MFMA fragments (8 fp16 = 4 VGPRs) of the hi and lo parts.
+// v_cvt_pkrtz_f16_f32 truncates, so lo = x - hi is exact and has the sign of x.
 __device__ __forceinline__ void split8(const float (&u)[8], uint4& hi, uint4& lo) {
     unsigned h[4], l[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        h[q] = pack_bf16x2(u[2 * q], u[2 * q + 1]);
-        const float h0 = __uint_as_float(h[q] << 16), h1 = __uint_as_float(h[q] & 0xffff0000u);
-        l[q] = pack_bf16x2(u[2 * q] - h0, u[2 * q + 1] - h1);
+        const auto hp = __builtin_amdgcn_cvt_pkrtz(u[2 * q], u[2 * q + 1]);
+        const float h0 = float(hp[0]), h1 = float(hp[1]);
+        const auto lp = __builtin_amdgcn_cvt_pkrtz(u[2 * q] - h0, u[2 * q + 1] - h1);
+        h[q] = __builtin_bit_cast(unsigned, hp);
+        l[q] = __builtin_bit_cast(unsigned, lp);
     }
     hi = make_uint4(h[0], h[1], h[2], h[3]);
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-__device__ __forceinline__ floatx16 mfma_bf(const uint4& a, const uint4& b, floatx16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+__device__ __forceinline__ floatx16 mfma_h(const uint4& a, const uint4& b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+
+// largest power of two s with bound * s < 2^15 (fp16 max 65504); 1 for inf/NaN bounds, clamped to 2^+-60
+__device__ __forceinline__ float scale_for(float bound) {
+    const int ex = int((__float_as_uint(bound) >> 23) & 0xffu);     // bound < 2^(ex - 126)
+    int f = 268 - ex;                                               // biased exponent of 2^(15 - (ex - 126))
+    f = min(max(f, 67), 187);
+    if (ex == 255) f = 127;
+    return __uint_as_float(unsigned(f) << 23);
+}
+
+// workgroup-wide max of non-negative floats into an LDS slot (slot zeroed earlier; read after a barrier)
+__device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
+    unsigned b = __float_as_uint(val);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
+    if (lane == 0) atomicMax(slot, b);
 }
 
 // row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
@@ -185,9 +208,11 @@ __device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, i
 
 // acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.  B: pre-loaded fragments.
 // PREC 0 (fp32 MFMA): A = LDS row `arow`, this lane supplies k = 64*hh + s.
-// PREC 1 (bf16x3):    this lane supplies k = 16*slab + 8*hh + e; b.q[slab] / b.q[8+slab] = hi / lo parts.
+// PREC 1 (f16x3):     this lane supplies k = 16*slab + 8*hh + e; b.q[slab] / b.q[8+slab] = hi / lo parts of the
+//                     pre-scaled weights; `sa` scales A into the fp16 range (acc is in units of sa*sw).
 template <int PREC>
-__device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh, const BFrag& b) {
+__device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh, const BFrag& b,
+                                          float sa) {
     if constexpr (PREC == 0) {
         const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
 #pragma unroll
@@ -204,13 +229,13 @@ __device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int 
         for (int slab = 0; slab < 8; ++slab) {
             const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * slab);
             const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * slab + 4);
-            const float u[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const float u[8] = {a0.x * sa, a0.y * sa, a0.z * sa, a0.w * sa, a1.x * sa, a1.y * sa, a1.z * sa, a1.w * sa};
             uint4 hi, lo;
             split8(u, hi, lo);
             const uint4 bh = __builtin_bit_cast(uint4, b.q[slab]), bl = __builtin_bit_cast(uint4, b.q[8 + slab]);
-            acc = mfma_bf(hi, bh, acc);
-            acc = mfma_bf(hi, bl, acc);
-            acc = mfma_bf(lo, bh, acc);
+            acc = mfma_h(lo, bh, acc);
+            acc = mfma_h(hi, bl, acc);
+            acc = mfma_h(hi, bh, acc);
         }
     }
 }
@@ -238,22 +263,30 @@ __device__ __forceinline__ void stage_store(const Lds& v, const StageRegs& r, in
 }
 
 // P[a][f] = b1'[f] + sum_k W1a'[f][k] H[a][k]  -> v.A ;  Q[a][f] = sum_k W1b'[f][k] H[a][k] -> v.B
+// f16x3: `sa` scales H, `inv` = 1/(sa*sw) rescales the accumulator; returns max |P| or |Q| this lane wrote.
 template <int PREC>
-__device__ __forceinline__ void node_pre(const Lds& v, int nb, int w, int lane, const BFrag& bf, float bias) {
+__device__ __forceinline__ float node_pre(const Lds& v, int nb, int w, int lane, const BFrag& bf, float bias,
+                                          float sa, float inv) {
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3;
     float* dst = (w < 4) ? v.A : v.B;
     const int mtiles = nb > 32 ? 2 : 1;
+    float vmax = 0.0f;
     for (int mt = 0; mt < mtiles; ++mt) {
-        floatx16 acc = splat16(bias);
+        floatx16 acc = splat16(PREC == 0 ? bias : 0.0f);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128<PREC>(acc, v.C, arow, hh, bf);
+        gemm_k128<PREC>(acc, v.C, arow, hh, bf, sa);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
-            if (row < nb) dst[row * LDH + 32 * nt + c] = acc[reg];
+            const float val = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias);
+            if (row < nb) {
+                dst[row * LDH + 32 * nt + c] = val;
+                vmax = fmaxf(vmax, fabsf(val));
+            }
         }
     }
+    return vmax;
 }
 
 // One pass over all n_b^2 ordered pairs of the molecule.
@@ -271,7 +304,7 @@ struct Spill {
 
 template <bool EQUIV, int PREC>
 __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask,
-                                            int N, float norm_constant) {
+                                            int N, float norm_constant, float sa, float acc_scale, float inv_scale) {
     const int c = lane & 31, hh = lane >> 5;
     const int npairs = nb * nb;
     const int ntiles = (npairs + 31) >> 5;
@@ -282,7 +315,7 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
     float bias[4], w7[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        bias[nt] = v.vec[2 * HID + 32 * nt + c];
+        bias[nt] = v.vec[2 * HID + 32 * nt + c] * (PREC == 0 ? 1.0f : acc_scale);
         w7[nt] = EQUIV ? v.vec[3 * HID + 32 * nt + c] : 0.0f;
     }
     const float4* wrp = reinterpret_cast<const float4*>(v.vec + 64 * hh);
@@ -356,7 +389,7 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
-            // ---- first edge layer as bf16 hi/lo A-fragments: lane = (pair c, k = 16*slab + 8*hh + e)
+            // ---- first edge layer as fp16 hi/lo A-fragments: lane = (pair c, k = 16*slab + 8*hh + e)
             uint4 ah[8], al[8];
             {
                 const float* Pp = v.A + i * LDH + 8 * hh;
@@ -373,15 +406,15 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
                         const float4 Q = *reinterpret_cast<const float4*>(Qp + k0);
                         const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
                         const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
-                        u[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
-                        u[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
-                        u[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
-                        u[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+                        u[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x))) * sa;
+                        u[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y))) * sa;
+                        u[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z))) * sa;
+                        u[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w))) * sa;
                     }
                     split8(u, ah[slab], al[slab]);
                 }
             }
-            // ---- second edge layer on the bf16 matrix pipe: per 16-k slab, 4 feature tiles x 3 split terms
+            // ---- second edge layer on the fp16 matrix pipe: per 16-k slab, 4 feature tiles x 3 split terms
             const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane;
 #pragma unroll
             for (int slab = 0; slab < 8; ++slab) {
@@ -391,12 +424,17 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
                     bh[nt] = Wq[(slab * 4 + nt) * 64];
                     bl[nt] = Wq[((8 + slab) * 4 + nt) * 64];
                 }
-                acc0 = mfma_bf(ah[slab], bh[0], acc0); acc1 = mfma_bf(ah[slab], bh[1], acc1);
-                acc2 = mfma_bf(ah[slab], bh[2], acc2); acc3 = mfma_bf(ah[slab], bh[3], acc3);
-                acc0 = mfma_bf(ah[slab], bl[0], acc0); acc1 = mfma_bf(ah[slab], bl[1], acc1);
-                acc2 = mfma_bf(ah[slab], bl[2], acc2); acc3 = mfma_bf(ah[slab], bl[3], acc3);
-                acc0 = mfma_bf(al[slab], bh[0], acc0); acc1 = mfma_bf(al[slab], bh[1], acc1);
-                acc2 = mfma_bf(al[slab], bh[2], acc2); acc3 = mfma_bf(al[slab], bh[3], acc3);
+                acc0 = mfma_h(al[slab], bh[0], acc0); acc1 = mfma_h(al[slab], bh[1], acc1);
+                acc2 = mfma_h(al[slab], bh[2], acc2); acc3 = mfma_h(al[slab], bh[3], acc3);
+                acc0 = mfma_h(ah[slab], bl[0], acc0); acc1 = mfma_h(ah[slab], bl[1], acc1);
+                acc2 = mfma_h(ah[slab], bl[2], acc2); acc3 = mfma_h(ah[slab], bl[3], acc3);
+                acc0 = mfma_h(ah[slab], bh[0], acc0); acc1 = mfma_h(ah[slab], bh[1], acc1);
+                acc2 = mfma_h(ah[slab], bh[2], acc2); acc3 = mfma_h(ah[slab], bh[3], acc3);
+            }
+            // back to the unscaled pre-activation (exact: inv_scale is a power of two)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                acc0[reg] *= inv_scale; acc1[reg] *= inv_scale; acc2[reg] *= inv_scale; acc3[reg] *= inv_scale;
             }
         }
         // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
@@ -512,19 +550,38 @@ __device__ __forceinline__ void spill_reduce(const Lds& v, int tid, bool equiv) 
     }
 }
 
+// exact reciprocal of a power of two
+__device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
+
+// f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
+constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, FM_X02 = 6;
+
+// scale of the edge-pass A-fragments: |u| <= |y| <= |P|+|Q| + r*|wr'| + d0*|wd'|,  r <= 4 max|x|^2
+__device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restrict__ sc) {
+    const float pq = __uint_as_float(v.fmax[FM_PQ]);
+    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+    return scale_for(2.0f * pq + 4.0f * (x2 * sc[6] + x02 * sc[7]));
+}
+
 // GCL (egnn.py:45-80) on the LDS-resident molecule; `hown` is this wave's 32x32 tile of h in registers.
+// `par` (f16x3): which of the two h-magnitude slots is current; toggled when h is rewritten.
 template <int PREC>
 __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ g,
-                                         floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf) {
+                                         floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf, int& par) {
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3, mt = w >> 2;
     const float* vecs = g + G_VEC;
+    const float* sc = g + G_SCALE;
     prof_event(pf, w, lane, 10);
+    if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; v.fmax[FM_T] = 0u; }
+    const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
     {
         // first-layer projections P,Q; the 64 KB W2' image streams from L2 underneath them
         const StageRegs st = stage_load(g + G_W2, vecs + HID, 3, tid);
         const BFrag bf = load_bfrag(g + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
-        node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
+        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
+        const float vmax = node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
+        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
         stage_store(v, st, 3, tid);
     }
     prof_event(pf, w, lane, 11);
@@ -532,10 +589,13 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
     for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
     __syncthreads();
     prof_event(pf, w, lane, 12);
-    const Spill sp = edge_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f);
+    float sa = 1.0f, accs = 1.0f;
+    if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
+    const Spill sp = edge_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, accs, inv_pow2(accs));
     prof_event(pf, w, lane, 13);
     const bool active = (mt == 0) || (nb > 32);
     __syncthreads();                       // every wave left the edge phase: P (v.A), Q (v.B) dead
+    if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
     spill_publish(v, sp, w, lane, false);
     __syncthreads();
     spill_reduce(v, tid, false);
@@ -545,40 +605,67 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         const int row = 32 * mt + acc_row(reg, hh);
         if (row < nb) v.A[row * LDH + 32 * nt + c] = hown[reg];
     }
+    if (PREC == 1) {
+        float am = 0.0f;
+        for (int e = tid; e < nb * HID; e += THREADS) am = fmaxf(am, fabsf(v.C[(e >> 7) * LDH + (e & (HID - 1))]));
+        block_max(&v.fmax[FM_AGG], am, lane);
+    }
     __syncthreads();
     prof_event(pf, w, lane, 14);
     // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
     if (active) {
         const BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
         const BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
-        floatx16 acc = splat16(vecs[4 * HID + 32 * nt + c]);
+        const float b3 = vecs[4 * HID + 32 * nt + c];
+        float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
+        if (PREC == 1) {
+            // one accumulator for both K-blocks: common total scale S = sa_i * sw_i
+            const float S = fminf(s_h * sc[2], scale_for(__uint_as_float(v.fmax[FM_AGG])) * sc[3]);
+            s1 = S * inv_pow2(sc[2]); s2 = S * inv_pow2(sc[3]); inv = inv_pow2(S);
+        }
+        floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128<PREC>(acc, v.A, arow, hh, b3a);
-        gemm_k128<PREC>(acc, v.C, arow, hh, b3b);
+        gemm_k128<PREC>(acc, v.A, arow, hh, b3a, s1);
+        gemm_k128<PREC>(acc, v.C, arow, hh, b3b, s2);
+        float tmax = 0.0f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
-            if (row < nb) v.B[row * LDH + 32 * nt + c] = silu_u(acc[reg]);
+            const float tval = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, b3));
+            if (row < nb) {
+                v.B[row * LDH + 32 * nt + c] = tval;
+                tmax = fmaxf(tmax, fabsf(tval));
+            }
         }
+        if (PREC == 1) block_max(&v.fmax[FM_T], tmax, lane);
     }
     prof_event(pf, w, lane, 15);
     __syncthreads();
     // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
     if (active) {
         const float b4 = vecs[5 * HID + 32 * nt + c];
+        const BFrag b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
+        float s_t = 1.0f, inv = 1.0f;
+        if (PREC == 1) { s_t = scale_for(__uint_as_float(v.fmax[FM_T])); inv = inv_pow2(s_t * sc[4]); }
         floatx16 acc;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) acc[reg] = hown[reg] + b4;
+        for (int reg = 0; reg < 16; ++reg) acc[reg] = (PREC == 0) ? hown[reg] + b4 : 0.0f;
         const int arow = min(32 * mt + c, nb - 1);
-        const BFrag b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
-        gemm_k128<PREC>(acc, v.B, arow, hh, b4f);
-        hown = acc;
+        gemm_k128<PREC>(acc, v.B, arow, hh, b4f, s_t);
+        float hmax = 0.0f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
-            if (row < nb) v.C[row * LDH + 32 * nt + c] = acc[reg];
+            const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hown[reg] + b4);
+            hown[reg] = hv;
+            if (row < nb) {
+                v.C[row * LDH + 32 * nt + c] = hv;
+                hmax = fmaxf(hmax, fabsf(hv));
+            }
         }
+        if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hmax, lane);
     }
+    par ^= 1;
     prof_event(pf, w, lane, 16);
     __syncthreads();
 }
@@ -586,29 +673,47 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
 // EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
 template <int PREC>
 __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ e,
-                                           const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf) {
+                                           const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf,
+                                           int par) {
     const int c = lane & 31;
     const int nt = w & 3;
     const float* vecs = e + E_VEC;
+    const float* sc = e + E_SCALE;
     prof_event(pf, w, lane, 30);
     {
+        const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
         const StageRegs st = stage_load(e + E_W6, vecs + HID, 4, tid);
         const BFrag bf = load_bfrag(e + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
-        node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f);
+        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
+        const float vmax = node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
+        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
         stage_store(v, st, 4, tid);
     }
     if (tid < 4 * nb) v.aggx[tid] = 0.0f;
     prof_event(pf, w, lane, 31);
     __syncthreads();
     prof_event(pf, w, lane, 32);
-    const Spill sp = edge_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant);
+    float sa = 1.0f, accs = 1.0f;
+    if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
+    const Spill sp = edge_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, accs, inv_pow2(accs));
     prof_event(pf, w, lane, 33);
     __syncthreads();
     spill_publish(v, sp, w, lane, true);
     __syncthreads();
     spill_reduce(v, tid, true);
+    if (PREC == 1 && tid == 0) { v.fmax[FM_PQ] = 0u; v.fmax[FM_X2] = 0u; }
     __syncthreads();
-    if (tid < 4 * nb && (tid & 3) < 3) v.xs[tid] += v.aggx[tid] * v.lm[tid >> 2];
+    float n2 = 0.0f;
+    if (tid < nb) {
+        const float lm = v.lm[tid];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float xn = v.xs[4 * tid + k] + v.aggx[4 * tid + k] * lm;
+            v.xs[4 * tid + k] = xn;
+            n2 = fmaf(xn, xn, n2);
+        }
+    }
+    if (PREC == 1) block_max(&v.fmax[FM_X2], n2, lane);
     prof_event(pf, w, lane, 34);
     __syncthreads();
 }
@@ -624,6 +729,10 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3, mt = w >> 2;
     prof_event(pf, w, lane, 1);
+    if (PREC == 1) {
+        if (tid < 8) v.fmax[tid] = 0u;
+        __syncthreads();
+    }
 
     // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
     if (tid < 4 * nb) {
@@ -631,6 +740,17 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
         const float xv = (k < 3) ? v.z[a * DMAX + k] : 0.0f;
         v.xs[tid] = xv;
         v.x0[tid] = xv;
+    }
+    if (PREC == 1) {
+        float n2 = 0.0f;
+        if (tid < nb) {
+            const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
+            n2 = x0 * x0 + x1 * x1 + x2 * x2;
+        }
+        unsigned b = __float_as_uint(n2);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
+        if (lane == 0) { atomicMax(&v.fmax[FM_X2], b); atomicMax(&v.fmax[FM_X02], b); }
     }
     // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224)
     {
@@ -643,6 +763,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
             wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
         }
         const float be = wp[OFF_EMB_B + f];
+        float hmax = 0.0f;
         for (int a = tid >> 7; a < nb; a += THREADS / HID) {
             float acc = be;
 #pragma unroll
@@ -654,7 +775,9 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
                 acc = fmaf(wrow[k], hin, acc);
             }
             v.C[a * LDH + f] = acc;
+            hmax = fmaxf(hmax, fabsf(acc));
         }
+        if (PREC == 1) block_max(&v.fmax[FM_H0], hmax, lane);
     }
     __syncthreads();
     floatx16 hown;
@@ -665,11 +788,13 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     }
     prof_event(pf, w, lane, 2);
 
+    int par = 0;
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) gcl_pass<PREC>(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf);
-        equiv_pass<PREC>(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf);
+        for (int gi = 0; gi < 2; ++gi)
+            gcl_pass<PREC>(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf, par);
+        equiv_pass<PREC>(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par);
     }
     prof_event(pf, w, lane, 3);
 
@@ -943,29 +1068,32 @@ void pack_lds_image(float* dst, const float* w, int ld, double scale) {
                 dst[(k * 32 + c) * 4 + nt] = float(double(w[size_t(32 * nt + c) * ld + k]) * scale);
 }
 
-inline uint16_t bf16_rne(float x) {                       // round-to-nearest-even fp32 -> bf16 bits
-    uint32_t u;
-    memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return uint16_t((u >> 16) | 0x40);   // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return uint16_t(u >> 16);
+// ---- f16x3 packing: W' = scale*W is multiplied by a power of two sw that puts max|W'| into [2^14, 2^15) and split
+// into fp16 hi (RNE) + lo (RNE of the exact remainder); the device rescales accumulators by 1/(sa*sw).
+inline double f16_weight_scale(const float* w, int ld, int col0, int ncols, double scale) {
+    double m = 0.0;
+    for (int f = 0; f < HID; ++f)
+        for (int k = 0; k < ncols; ++k) m = fmax(m, fabs(double(w[size_t(f) * ld + col0 + k]) * scale));
+    if (!(m > 0.0) || !std::isfinite(m)) return 1.0;
+    int e;
+    frexp(m, &e);                                    // m < 2^e
+    e = 15 - e;
+    if (e > 60) e = 60;
+    if (e < -60) e = -60;
+    return ldexp(1.0, e);
 }
-inline float bf16_to_float(uint16_t h) {
-    uint32_t u = uint32_t(h) << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// hi/lo bf16 parts of scale*W[f][k]
-inline void split_bf16(double v, uint16_t& hi, uint16_t& lo) {
+inline void split_f16(double v, uint16_t& hi, uint16_t& lo) {
     const float x = float(v);
-    hi = bf16_rne(x);
-    lo = bf16_rne(x - bf16_to_float(hi));
+    const _Float16 h = static_cast<_Float16>(x);
+    const _Float16 l = static_cast<_Float16>(x - static_cast<float>(h));
+    memcpy(&hi, &h, 2);
+    memcpy(&lo, &l, 2);
 }
 
-// bf16x3 node-fragment order: unit[nt][part*8 + slab][lane][e] (bf16), value = part(W[f = 32nt + (lane&31)][k]),
+// f16x3 node-fragment order: unit[nt][part*8 + slab][lane][e] (fp16), value = part(sw*W'[f = 32nt + (lane&31)][k]),
 // k = 16*slab + 8*(lane>>5) + e; same bytes as the fp32 unit (64 KB), read as 16 x dwordx4 per lane
-void pack_unit_bf16(float* dstf, const float* w, int ld, int col0, double scale) {
+double pack_unit_f16(float* dstf, const float* w, int ld, int col0, double scale) {
+    const double sw = f16_weight_scale(w, ld, col0, HID, scale);
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
     for (int nt = 0; nt < 4; ++nt)
         for (int slab = 0; slab < 8; ++slab)
@@ -974,14 +1102,16 @@ void pack_unit_bf16(float* dstf, const float* w, int ld, int col0, double scale)
                     const int f = 32 * nt + (lane & 31);
                     const int k = 16 * slab + 8 * (lane >> 5) + e;
                     uint16_t hi, lo;
-                    split_bf16(double(w[size_t(f) * ld + col0 + k]) * scale, hi, lo);
+                    split_f16(double(w[size_t(f) * ld + col0 + k]) * scale * sw, hi, lo);
                     dst[(((nt * 16 + slab) * 64 + lane) * 8) + e] = hi;
                     dst[(((nt * 16 + 8 + slab) * 64 + lane) * 8) + e] = lo;
                 }
+    return sw;
 }
 
-// bf16x3 LDS image: img[part*8 + slab][nt][lane][e]
-void pack_lds_image_bf16(float* dstf, const float* w, int ld, double scale) {
+// f16x3 LDS image: img[part*8 + slab][nt][lane][e]
+double pack_lds_image_f16(float* dstf, const float* w, int ld, double scale) {
+    const double sw = f16_weight_scale(w, ld, 0, HID, scale);
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
     for (int slab = 0; slab < 8; ++slab)
         for (int nt = 0; nt < 4; ++nt)
@@ -990,10 +1120,17 @@ void pack_lds_image_bf16(float* dstf, const float* w, int ld, double scale) {
                     const int f = 32 * nt + (lane & 31);
                     const int k = 16 * slab + 8 * (lane >> 5) + e;
                     uint16_t hi, lo;
-                    split_bf16(double(w[size_t(f) * ld + k]) * scale, hi, lo);
+                    split_f16(double(w[size_t(f) * ld + k]) * scale * sw, hi, lo);
                     dst[(((slab * 4 + nt) * 64 + lane) * 8) + e] = hi;
                     dst[((((8 + slab) * 4 + nt) * 64 + lane) * 8) + e] = lo;
                 }
+    return sw;
+}
+
+float vec_absmax(const float* v) {
+    float m = 0.0f;
+    for (int f = 0; f < HID; ++f) m = fmaxf(m, fabsf(v[f]));
+    return m;
 }
 
 void pack_vec(float* dst, const float* src, int stride, double scale) {
@@ -1037,7 +1174,7 @@ static int32_t check_cfg(const dl_config* c) {
     if (c->in_node_nf + 1 + c->context_node_nf > FINP) return DL_ERR_UNSUPPORTED;
     if (c->n_layers < 1 || c->n_layers > 64) return DL_ERR_UNSUPPORTED;
     if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
-    if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_BF16X3) return DL_ERR_UNSUPPORTED;
+    if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_F16X3) return DL_ERR_UNSUPPORTED;
     return DL_OK;
 }
 
@@ -1056,12 +1193,16 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     const size_t total = size_t(OFF_BLOCKS) + size_t(L) * BLOCK_SIZE;
     float* hp = static_cast<float*>(calloc(total, sizeof(float)));
     if (!hp) return DL_ERR_ALLOC;
-    const bool bf = cfg->precision == DL_PRECISION_BF16X3;
-    auto unit = [&](float* d, const float* ww, int ld, int col0, double sc) {
-        if (bf) pack_unit_bf16(d, ww, ld, col0, sc); else pack_unit(d, ww, ld, col0, sc);
+    const bool f16 = cfg->precision == DL_PRECISION_F16X3;
+    auto unit = [&](float* d, const float* ww, int ld, int col0, double sc) -> float {
+        if (f16) return float(pack_unit_f16(d, ww, ld, col0, sc));
+        pack_unit(d, ww, ld, col0, sc);
+        return 1.0f;
     };
-    auto image = [&](float* d, const float* ww, int ld, double sc) {
-        if (bf) pack_lds_image_bf16(d, ww, ld, sc); else pack_lds_image(d, ww, ld, sc);
+    auto image = [&](float* d, const float* ww, int ld, double sc) -> float {
+        if (f16) return float(pack_lds_image_f16(d, ww, ld, sc));
+        pack_lds_image(d, ww, ld, sc);
+        return 1.0f;
     };
     const double c = -1.4426950408889634;            // -log2(e): y = c * pre-activation
     const double inv_norm = 1.0 / double(cfg->normalization_factor);
@@ -1086,12 +1227,13 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             const float* w3 = w[ti++]; const float* b3 = w[ti++];     // node_mlp.0 [128][256]
             const float* w4 = w[ti++]; const float* b4 = w[ti++];     // node_mlp.2 [128][128]
             const int ld1 = 2 * HID + 2;
-            unit(g + G_W1A, w1, ld1, 0, c);
-            unit(g + G_W1B, w1, ld1, HID, c);
-            unit(g + G_W3A, w3, 2 * HID, 0, c);
-            unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);         // agg arrives as c*norm*true agg
-            unit(g + G_W4, w4, HID, 0, 1.0 / c);
-            image(g + G_W2, w2, HID, 1.0);
+            float* sc = g + G_SCALE;
+            sc[0] = unit(g + G_W1A, w1, ld1, 0, c);
+            sc[1] = unit(g + G_W1B, w1, ld1, HID, c);
+            sc[2] = unit(g + G_W3A, w3, 2 * HID, 0, c);
+            sc[3] = unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);      // agg arrives as c*norm*true agg
+            sc[4] = unit(g + G_W4, w4, HID, 0, 1.0 / c);
+            sc[5] = image(g + G_W2, w2, HID, 1.0);
             float* vv = g + G_VEC;
             pack_vec(vv + 0 * HID, b1, 1, c);
             pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);             // radial column
@@ -1099,21 +1241,26 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             pack_vec(vv + 3 * HID, b2, 1, c);
             pack_vec(vv + 4 * HID, b3, 1, c);
             pack_vec(vv + 5 * HID, b4, 1, 1.0);
+            sc[6] = vec_absmax(vv + 1 * HID);
+            sc[7] = vec_absmax(vv + 2 * HID);
         }
         float* e = base + 2 * GCL_SIZE;
         const float* w5 = w[ti++]; const float* b5 = w[ti++];         // coord_mlp.0 [128][258]
         const float* w6 = w[ti++]; const float* b6 = w[ti++];         // coord_mlp.2 [128][128]
         const float* w7 = w[ti++];                                    // coord_mlp.4 [1][128], no bias
         const int ld5 = 2 * HID + 2;
-        unit(e + E_W5A, w5, ld5, 0, c);
-        unit(e + E_W5B, w5, ld5, HID, c);
-        image(e + E_W6, w6, HID, 1.0);
+        float* sc = e + E_SCALE;
+        sc[0] = unit(e + E_W5A, w5, ld5, 0, c);
+        sc[1] = unit(e + E_W5B, w5, ld5, HID, c);
+        sc[2] = image(e + E_W6, w6, HID, 1.0);
         float* vv = e + E_VEC;
         pack_vec(vv + 0 * HID, b5, 1, c);
         pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
         pack_vec(vv + 2 * HID, w5 + 2 * HID + 1, ld5, c);
         pack_vec(vv + 3 * HID, b6, 1, c);
         pack_vec(vv + 4 * HID, w7, 1, inv_norm / c);
+        sc[6] = vec_absmax(vv + 1 * HID);
+        sc[7] = vec_absmax(vv + 2 * HID);
     }
     dl_model* m = static_cast<dl_model*>(calloc(1, sizeof(dl_model)));
     if (!m) { free(hp); return DL_ERR_ALLOC; }
@@ -1169,7 +1316,7 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float*
     a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
     a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
     a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags; a.prof = g_prof_buf;
-    if (m->cfg.precision == DL_PRECISION_BF16X3)
+    if (m->cfg.precision == DL_PRECISION_F16X3)
         hipLaunchKernelGGL(egnn_forward_fc_kernel<1>, dim3(B), dim3(THREADS), LDS_BYTES,
                            static_cast<hipStream_t>(stream), a);
     else
@@ -1187,7 +1334,7 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if (g->B == 0) return DL_OK;
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
-    if (m->cfg.precision == DL_PRECISION_BF16X3)
+    if (m->cfg.precision == DL_PRECISION_F16X3)
         hipLaunchKernelGGL(sample_chain_fc_kernel<1>, dim3(g->B), dim3(THREADS), LDS_BYTES,
                            static_cast<hipStream_t>(stream), a);
     else

@@ -175,9 +175,9 @@ class Dynamics(nn.Module):
         self.n_layers = n_layers
         self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
         self._hip_models = {}                          # device index -> (_HipModel, weight version)
-        # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'bf16x3' = split-bf16 on the
+        # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'f16x3' = scaled split-fp16 on the
         # matrix cores (default, ~3e-6 rel-L2 on a 500-step chain), 'fp32' = exact fp32 MFMA.
-        self.precision = os.environ.get('DIFFLINKER_PRECISION', 'bf16x3')
+        self.precision = os.environ.get('DIFFLINKER_PRECISION', 'f16x3')
 
     # ---- packed weights -----------------------------------------------------------------------------
     def _weight_version(self):

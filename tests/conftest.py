@@ -10,6 +10,8 @@ for p in (ROOT, os.path.dirname(os.path.abspath(__file__))):
 
 
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the CPU oracle gets slower beyond ~16 threads
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
