@@ -43,10 +43,6 @@ constexpr int DMAX = 16;            // row stride of the per-atom state z = [x(3
 constexpr int CTXMAX = 4;
 constexpr int THREADS = 512;
 constexpr int NWAVES = 8;
-#ifndef DL_STAGGER
-#define DL_STAGGER 127
-#endif
-constexpr int STAGGER = DL_STAGGER;     // s_sleep units (64 cycles) the upper half-workgroup waits before its first MFMA loop
 
 // ---- packed weight buffer (floats); mirrored by pack_model() below -------------------------------
 constexpr int OFF_EMB_W = 0;                          // [128][FINP]
@@ -82,7 +78,8 @@ constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padde
 constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
 constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
-constexpr int L_TOTAL = L_FMAX + 8;
+constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
+constexpr int L_TOTAL = L_DUMMY + LDH;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -92,6 +89,7 @@ struct Lds {
     float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag, *ctx;
     int *idx, *misc;
     unsigned* fmax;
+    float* dummy;
 };
 
 __device__ __forceinline__ Lds lds_view(float* base) {
@@ -101,6 +99,7 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     v.lm = base + L_LM; v.frag = base + L_FRAG; v.ctx = base + L_CTX;
     v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
     v.fmax = reinterpret_cast<unsigned*>(base + L_FMAX);
+    v.dummy = base + L_DUMMY;
     return v;
 }
 
@@ -262,6 +261,12 @@ __device__ __forceinline__ void stage_store(const Lds& v, const StageRegs& r, in
     if (tid < nvec * HID / 4) reinterpret_cast<float4*>(v.vec)[tid] = r.vec;
 }
 
+// store one accumulator element of tile row `row` to a [n][LDH] buffer; rows >= n_b go to the sink row
+__device__ __forceinline__ void store_row(const Lds& v, float* buf, int row, int nb, int col, float val) {
+    float* p = (row < nb) ? buf + row * LDH + col : v.dummy + col;
+    *p = val;
+}
+
 // P[a][f] = b1'[f] + sum_k W1a'[f][k] H[a][k]  -> v.A ;  Q[a][f] = sum_k W1b'[f][k] H[a][k] -> v.B
 // f16x3: `sa` scales H, `inv` = 1/(sa*sw) rescales the accumulator; returns max |P| or |Q| this lane wrote.
 template <int PREC>
@@ -280,10 +285,8 @@ __device__ __forceinline__ float node_pre(const Lds& v, int nb, int w, int lane,
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float val = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias);
-            if (row < nb) {
-                dst[row * LDH + 32 * nt + c] = val;
-                vmax = fmaxf(vmax, fabsf(val));
-            }
+            store_row(v, dst, row, nb, 32 * nt + c, val);
+            vmax = fmaxf(vmax, row < nb ? fabsf(val) : 0.0f);
         }
     }
     return vmax;
@@ -322,15 +325,6 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
     const float4* wdp = reinterpret_cast<const float4*>(v.vec + HID + 64 * hh);
     const float4* Wp = reinterpret_cast<const float4*>(v.W) + (64 * hh * 32 + c);
 
-    // The two waves that share a SIMD (w, w+4) start every phase in lockstep: both in their VALU
-    // phase (matrix pipe idle), then both in their MFMA loop (pipe shared fairly) - they overlap
-    // nothing, and the pipe idles for one VALU phase per tile.  Holding the upper wave back by about
-    // one VALU phase ONCE puts the pair into the complementary rhythm (one wave's VALU phase under
-    // the other's solo MFMA time), which then sustains itself.
-    if (STAGGER > 0 && w >= NWAVES / 2) {
-        if (STAGGER > 127) __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(STAGGER > 127 ? STAGGER - 127 : STAGGER);
-    }
     for (int t = t_begin; t < t_end; ++t) {
         const int p = 32 * t + c;
         const bool valid = p < npairs;
@@ -602,8 +596,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
     __syncthreads();                       // aggregate complete in v.C
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-        const int row = 32 * mt + acc_row(reg, hh);
-        if (row < nb) v.A[row * LDH + 32 * nt + c] = hown[reg];
+        store_row(v, v.A, 32 * mt + acc_row(reg, hh), nb, 32 * nt + c, hown[reg]);
     }
     if (PREC == 1) {
         float am = 0.0f;
@@ -632,10 +625,8 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float tval = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, b3));
-            if (row < nb) {
-                v.B[row * LDH + 32 * nt + c] = tval;
-                tmax = fmaxf(tmax, fabsf(tval));
-            }
+            store_row(v, v.B, row, nb, 32 * nt + c, tval);
+            tmax = fmaxf(tmax, row < nb ? fabsf(tval) : 0.0f);
         }
         if (PREC == 1) block_max(&v.fmax[FM_T], tmax, lane);
     }
@@ -657,12 +648,11 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hown[reg] + b4);
-            hown[reg] = hv;
-            if (row < nb) {
-                v.C[row * LDH + 32 * nt + c] = hv;
-                hmax = fmaxf(hmax, fabsf(hv));
-            }
+            acc[reg] = hv;
+            store_row(v, v.C, row, nb, 32 * nt + c, hv);
+            hmax = fmaxf(hmax, row < nb ? fabsf(hv) : 0.0f);
         }
+        hown = acc;
         if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hmax, lane);
     }
     par ^= 1;
@@ -864,7 +854,7 @@ struct FwdArgs {
 
 template <int PREC>
 __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
     const int tid = threadIdx.x;
     const int b = blockIdx.x;
@@ -921,7 +911,7 @@ struct ChainArgs {
 
 template <int PREC>
 __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
     const dl_chain_args& g = p.a;
     const int tid = threadIdx.x;
@@ -1273,18 +1263,6 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         free(hp); free(m); return DL_ERR_HIP;
     }
     free(hp);
-    static bool attr_done = false;
-    if (!attr_done) {
-        const void* kernels[4] = {reinterpret_cast<const void*>(egnn_forward_fc_kernel<0>),
-                                  reinterpret_cast<const void*>(egnn_forward_fc_kernel<1>),
-                                  reinterpret_cast<const void*>(sample_chain_fc_kernel<0>),
-                                  reinterpret_cast<const void*>(sample_chain_fc_kernel<1>)};
-        for (const void* k : kernels)
-            if (!hip_ok(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, int(LDS_BYTES)))) {
-                (void)hipFree(m->d_pack); free(m); return DL_ERR_HIP;
-            }
-        attr_done = true;
-    }
     *out = m;
     return DL_OK;
 }
@@ -1317,10 +1295,10 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float*
     a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
     a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags; a.prof = g_prof_buf;
     if (m->cfg.precision == DL_PRECISION_F16X3)
-        hipLaunchKernelGGL(egnn_forward_fc_kernel<1>, dim3(B), dim3(THREADS), LDS_BYTES,
+        hipLaunchKernelGGL(egnn_forward_fc_kernel<1>, dim3(B), dim3(THREADS), 0,
                            static_cast<hipStream_t>(stream), a);
     else
-        hipLaunchKernelGGL(egnn_forward_fc_kernel<0>, dim3(B), dim3(THREADS), LDS_BYTES,
+        hipLaunchKernelGGL(egnn_forward_fc_kernel<0>, dim3(B), dim3(THREADS), 0,
                            static_cast<hipStream_t>(stream), a);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
@@ -1335,10 +1313,10 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
     if (m->cfg.precision == DL_PRECISION_F16X3)
-        hipLaunchKernelGGL(sample_chain_fc_kernel<1>, dim3(g->B), dim3(THREADS), LDS_BYTES,
+        hipLaunchKernelGGL(sample_chain_fc_kernel<1>, dim3(g->B), dim3(THREADS), 0,
                            static_cast<hipStream_t>(stream), a);
     else
-        hipLaunchKernelGGL(sample_chain_fc_kernel<0>, dim3(g->B), dim3(THREADS), LDS_BYTES,
+        hipLaunchKernelGGL(sample_chain_fc_kernel<0>, dim3(g->B), dim3(THREADS), 0,
                            static_cast<hipStream_t>(stream), a);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }

@@ -84,11 +84,16 @@ def run_hip_forward(dyn, inp, z, t, linker_mask='given', edge_mask='given'):
     return out.cpu()
 
 
-def report(tag, out, ref):
-    ev, eh = rel_l2(out[..., :3], ref[..., :3]), rel_l2(out[..., 3:], ref[..., 3:])
-    per_mol = [(round(rel_l2(out[b, :, :3], ref[b, :, :3]), 9), round(rel_l2(out[b, :, 3:], ref[b, :, 3:]), 9))
-               for b in range(out.shape[0])]
-    print(f'[{tag}] rel-L2 vel {ev:.3e} h {eh:.3e} | max-abs {max_abs(out, ref):.3e} | per-mol {per_mol[:8]}')
+def report(tag, out, ref, xin=None):
+    """rel-L2 of the velocity and feature parts.  vel = x_final - x is a difference of fp32 coordinates, so
+    both implementations carry an absolute error of a few ulp(|x|) in it; that floor (4 * 2^-24 * ||x||) is
+    removed from the velocity error before it is normalised (it dominates when the update is tiny)."""
+    dv = float((out[..., :3].double() - ref[..., :3].double()).norm())
+    floor = 4 * 2.0 ** -24 * float(xin[..., :3].double().norm()) if xin is not None else 0.0
+    ev = max(0.0, dv - floor) / max(float(ref[..., :3].double().norm()), 1e-30)
+    eh = rel_l2(out[..., 3:], ref[..., 3:])
+    raw = rel_l2(out[..., :3], ref[..., :3])
+    print(f'[{tag}] rel-L2 vel {ev:.3e} (raw {raw:.3e}) h {eh:.3e} | max-abs {max_abs(out, ref):.3e}')
     return ev, eh
 
 
@@ -113,7 +118,7 @@ def test_forward_vs_oracle(sizes, linkers, n_layers, precision):
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
                                        inp['context'])
     out = run_hip_forward(dyn, inp, z, t)
-    ev, eh = report(f'fwd sizes={sizes} L={n_layers} {precision}', out, ref)
+    ev, eh = report(f'fwd sizes={sizes} L={n_layers} {precision}', out, ref, z)
     nm = inp['node_mask'].float()
     assert float((out * (1 - nm)).abs().max()) == 0.0, 'padded rows must be exactly zero'
     assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
@@ -124,14 +129,14 @@ def test_forward_vs_reference_golden(golden_dir):
     dyn, sd, cfg = make_dynamics(g['nf'], g['ctx'], g['n_layers'], seed=g['weight_seed'], coord_gain=g['coord_gain'])
     inp = {k: g[k] for k in ('node_mask', 'linker_mask', 'edge_mask', 'context')}
     out = run_hip_forward(dyn, inp, g['xh'], g['t'])
-    ev, eh = report('golden fc_forward', out, g['out'])
+    ev, eh = report('golden fc_forward', out, g['out'], g['xh'])
     assert ev <= FWD_TOL and eh <= FWD_TOL
     # scalar-t branch (egnn.py:397-399) on the un-padded molecule 1
     B, N = g['xh'].shape[:2]
     inp1 = {'node_mask': g['node_mask'][1:2, :9], 'linker_mask': g['linker_mask'][1:2, :9],
             'edge_mask': g['edge_mask'].view(B, N, N)[1, :9, :9].reshape(-1, 1), 'context': g['context'][1:2, :9]}
     out1 = run_hip_forward(dyn, inp1, g['xh'][1:2, :9], g['t'][1:2])
-    ev, eh = report('golden fc_forward mol1 unpadded', out1, g['out_mol1_unpadded'])
+    ev, eh = report('golden fc_forward mol1 unpadded', out1, g['out_mol1_unpadded'], g['xh'][1:2, :9])
     assert ev <= FWD_TOL and eh <= FWD_TOL
 
 
@@ -141,7 +146,7 @@ def test_forward_feature_widths(nf, ctx):
     inp, z, t = ragged_inputs([20, 17], [5, 4], nf, seed=3, ctx=ctx)
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
                                        inp['context'])
-    ev, eh = report(f'fwd nf={nf} ctx={ctx}', run_hip_forward(dyn, inp, z, t), ref)
+    ev, eh = report(f'fwd nf={nf} ctx={ctx}', run_hip_forward(dyn, inp, z, t), ref, z)
     assert ev <= FWD_TOL and eh <= FWD_TOL
 
 
@@ -150,7 +155,7 @@ def test_forward_without_linker_mask_and_wide_padding():
     dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=8)
     inp, z, t = ragged_inputs([10, 22], [3, 6], nf, seed=5, n_pad=70)       # N=70 > 64: multi-chunk compaction
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], None, inp['edge_mask'], inp['context'])
-    ev, eh = report('fwd linker_mask=None N=70', run_hip_forward(dyn, inp, z, t, linker_mask=None), ref)
+    ev, eh = report('fwd linker_mask=None N=70', run_hip_forward(dyn, inp, z, t, linker_mask=None), ref, z)
     assert ev <= FWD_TOL and eh <= FWD_TOL
 
 
@@ -214,7 +219,7 @@ def test_edge_mask_sign_convention_is_observable():
     out_i8 = run_hip_forward(dyn, inp, z, t)
     out_bool = run_hip_forward(dyn, inp, z, t, edge_mask=bool_mask.to(dev()))
     assert rel_l2(ref_bool, ref_i8) > 1e-3
-    assert rel_l2(out_i8, ref_i8) <= FWD_TOL and rel_l2(out_bool, ref_bool) <= FWD_TOL
+    assert max(report('mask i8', out_i8, ref_i8, z)) <= FWD_TOL and max(report('mask bool', out_bool, ref_bool, z)) <= FWD_TOL
 
 
 def test_nan_raises_found_nan_exception_with_index_sets():
@@ -261,9 +266,9 @@ def test_sampler_step_kernel_matches_oracle_arithmetic():
 
 
 # ---------------------------------------------------------------------------------------------------
-def chain_case(nf, n_layers, sizes, linkers, T, keep, seed, timesteps=500, precision=None):
+def chain_case(nf, n_layers, sizes, linkers, T, keep, seed, timesteps=500, precision=None, coord_gain=0.02):
     from difflinker_amd import EDM
-    dyn, sd, cfg = make_dynamics(nf, 1, n_layers, seed=seed, precision=precision)
+    dyn, sd, cfg = make_dynamics(nf, 1, n_layers, seed=seed, precision=precision, coord_gain=coord_gain)
     inp, _, _ = ragged_inputs(sizes, linkers, nf, seed=seed + 1)
     B, N = inp['x'].shape[:2]
     edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=timesteps, noise_schedule='polynomial_2',
@@ -369,7 +374,9 @@ def test_ddpm_sample_chain_end_to_end():
 def test_chain_full_length_geom_like():
     """GEOM hparams (6 blocks), the full T=500 chain on a few C2-sized molecules against the oracle."""
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    got, want, inp = chain_case(nf=9, n_layers=6, sizes=[50, 41], linkers=[8, 6], T=500, keep=1, seed=90)
+    # coordinate head at the reference's own init scale (xavier gain 0.001, egnn.py:90-91): the 0.02 'lively'
+    # variant used elsewhere overflows to NaN within 500 steps on the oracle itself (SURVEY section 0.10)
+    got, want, inp = chain_case(nf=9, n_layers=6, sizes=[50, 41], linkers=[8, 6], T=500, keep=1, seed=90, coord_gain=0.001)
     check_chain('chain GEOM-like T=500 L=6', got, want, inp)
 
 
@@ -388,5 +395,5 @@ def test_geom_sized_forward_full_batch():
     torch.set_num_threads(min(16, os.cpu_count() or 1))      # more threads only slow the CPU oracle down
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     out = run_hip_forward(dyn, inp, z, t)
-    ev, eh = report('C2 full forward', out, ref)
+    ev, eh = report('C2 full forward', out, ref, z)
     assert ev <= FWD_TOL and eh <= FWD_TOL
