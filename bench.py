@@ -30,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
+F16_MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense BF16/F16 MFMA peak (spec)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -158,11 +159,20 @@ def main():
         achieved = flops_fwd * (cfg['T'] + 1) / (k_avg_ms * 1e-3) / 1e12
         layer_bytes = synthetic.layer_bytes(nodes, pairs)
         t_layer = k_avg_ms * 1e-3 / ((cfg['T'] + 1) * cfg['n_layers'])
+        precision = edm.dynamics.precision
+        if precision == 'f16x3':
+            # the 128-wide contractions run as 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
+            # ALGORITHMIC-flop ceiling of the scheme is the dense f16 MFMA peak / 3
+            peak, peak_note = F16_MFMA_PEAK_TFLOPS / 3.0, \
+                'dense f16 MFMA peak 2500 TFLOP/s / 3 split terms (fp32-equivalent result); the kernel is bound by ' \
+                'v_exp_f32/v_rcp_f32 throughput (2 SiLU per pair and channel), not by the matrix pipe'
+        else:
+            peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
         out = {
             'metric': 'molecules/sec (500-step sample_chain)', 'value': B * world * a.steps / elapsed,
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic',
             'config': {'workload': f'{a.config}: GEOM geom_difflinker hparams (egnn_dynamics, hidden 128, '
                                    f'{cfg["n_layers"]} blocks), batch={B} molecules/GPU padded to N={N} '
                                    f'(n_b {"= N" if a.uniform_size else "~ U{35..50}"}), T={cfg["T"]} reverse steps '
@@ -170,14 +180,15 @@ def main():
                                    f'fragment graphs',
                        'global_batch': B * world, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}',
                        'real_pairs_per_forward': pairs, 'real_atoms': nodes},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': None, 'peak_note': peak_note,
+                         'frac_of_fp32_vector_peak': achieved / FP32_MFMA_PEAK_TFLOPS,
                          'kernel': 'sample_chain_fc_kernel', 'kernel_ms': k_avg_ms,
                          'flops_per_launch': flops_fwd * (cfg['T'] + 1)},
             'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
-                          'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the fused '
-                                  'kernel is fp32-MFMA-bound, HBM fraction is expected << 1 %'},
+                          'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '
+                                  'LDS-resident for the whole chain, so the HBM fraction is << 1 % by design'},
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(edm, cfg, inp_cpu, a.cpu_forwards)

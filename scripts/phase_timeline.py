@@ -66,6 +66,7 @@ for w in range(8):
         nm = names.get(key, str(key))
         tot[nm] = tot.get(nm, 0) + int(e[k + 1, 1] - e[k, 1])
     total = int(e[n - 1, 1] - e[0, 1])
+    print(f'wave {w}: gcl EDGE {tot.get("gcl: EDGE tiles", 0):9d}  eq EDGE {tot.get("eq: EDGE tiles", 0):9d}  total {total}')
     if w in (0, 3, 7):
         print(f'--- wave {w}: {n} events, total {total} ticks')
         for nm, v in tot.items():
