@@ -48,7 +48,7 @@ class DLChainArgs(ctypes.Structure):
 
 EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_string', 'dl_model_num_tensors',
            'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
-           'dl_set_profile_buffer', 'dl_profile_max_events')
+           'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket')
 
 _lib = None
 
@@ -89,6 +89,10 @@ def load():
     lib.dl_set_profile_buffer.restype = None
     lib.dl_set_profile_buffer.argtypes = [vp]
     lib.dl_profile_max_events.restype = i32
+    lib.dl_pocket_workspace_bytes.restype = ctypes.c_size_t
+    lib.dl_pocket_workspace_bytes.argtypes = [i32, i32]
+    lib.dl_egnn_forward_pocket.restype = i32
+    lib.dl_egnn_forward_pocket.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dl_sample_chain_fc.restype = i32
     lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
     _lib = lib

@@ -29,42 +29,18 @@
 #include <cmath>
 
 #include "../../include/difflinker_hip.h"
+#include "pack_layout.h"
 
 namespace {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int HID = 128;            // hidden_nf
 constexpr int LDH = 132;            // LDS row stride of [n,128] fp32 tiles: 528 B = 33 x 16 B (conflict-free b128)
 constexpr int NMAX = 55;            // real atoms per molecule that fit the LDS-resident layout
-constexpr int UNIT = HID * HID;     // one packed 128x128 matrix
-constexpr int FINP = 16;            // embedding input width, padded
-constexpr int DMAX = 16;            // row stride of the per-atom state z = [x(3), h(nf)], 3+nf <= 16
-constexpr int CTXMAX = 4;
 constexpr int THREADS = 512;
 constexpr int NWAVES = 8;
 #ifndef DL_LOWER_SHARE
 #define DL_LOWER_SHARE 9
 #endif
 constexpr int LOWER_SHARE = DL_LOWER_SHARE;   // of 16: tiles of a SIMD's wave pair given to its older wave (8 = even split)
-
-// ---- packed weight buffer (floats); mirrored by pack_model() below -------------------------------
-constexpr int OFF_EMB_W = 0;                          // [128][FINP]
-constexpr int OFF_EMB_B = OFF_EMB_W + HID * FINP;     // [128]
-constexpr int OFF_OUT_W = OFF_EMB_B + HID;            // [16][128]
-constexpr int OFF_OUT_B = OFF_OUT_W + 16 * HID;       // [16]
-constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
-// GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image), vectors
-constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT;
-constexpr int G_VEC = 6 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
-constexpr int G_SCALE = G_VEC + 6 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max
-constexpr int GCL_SIZE = 6 * UNIT + 6 * HID + 8;
-// equivariant update: units W5a', W5b', W6' (LDS image), vectors
-constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT;
-constexpr int E_VEC = 3 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
-constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max
-constexpr int EQ_SIZE = 3 * UNIT + 5 * HID + 8;
-constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
 
 // ---- LDS layout (floats) ---------------------------------------------------------------------------
 constexpr int L_A = 0;                                // P  / h row-major / eps (aliased at the end)
@@ -107,11 +83,6 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     return v;
 }
 
-struct ModelDims {
-    int nf, ctx, fin, n_layers;
-    float norm_constant;
-};
-
 // Optional phase timeline (diagnostics, dl_set_profile_buffer): lane 0 of every wave of block 0 logs
 // (tag, s_memtime) pairs into buf[wave][event][2]; buf == nullptr (the normal case) costs one
 // wave-uniform branch per phase.
@@ -129,22 +100,6 @@ __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
         }
         pf.n++;
     }
-}
-
-// u = y * sigmoid(-y / log2e)  ==  -log2(e) * SiLU(pre)  for  y = -log2(e) * pre
-__device__ __forceinline__ float silu_u(float y) {
-    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
-}
-
-__device__ __forceinline__ floatx16 splat16(float v) {
-    floatx16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = v;
-    return r;
-}
-
-__device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
 // ---- f16x3 path (PREC 1): every fp32 operand of a 128-wide contraction is scaled by a power of two into the
@@ -192,21 +147,6 @@ __device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
     if (lane == 0) atomicMax(slot, b);
-}
-
-// row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
-__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
-
-// B fragments of one packed unit slice (one 32-feature tile, K = 128): 16 x dwordx4 per lane from L2.
-struct BFrag {
-    float4 q[16];
-};
-__device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, int lane) {
-    BFrag b;
-    const float4* bp = reinterpret_cast<const float4*>(unit_nt) + lane;
-#pragma unroll
-    for (int sg = 0; sg < 16; ++sg) b.q[sg] = bp[sg * 64];
-    return b;
 }
 
 // acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.  B: pre-loaded fragments.
@@ -1140,12 +1080,6 @@ void pack_vec(float* dst, const float* src, int stride, double scale) {
 
 }  // namespace
 
-struct dl_model {
-    dl_config cfg;
-    float* d_pack;
-    size_t n_floats;
-};
-
 extern "C" {
 
 int32_t dl_abi_version(void) { return DL_ABI_VERSION; }
@@ -1282,16 +1216,6 @@ void dl_model_destroy(dl_model* m) {
     if (!m) return;
     if (m->d_pack) (void)hipFree(m->d_pack);
     free(m);
-}
-
-static ModelDims dims_of(const dl_model* m) {
-    ModelDims md;
-    md.nf = m->cfg.in_node_nf;
-    md.ctx = m->cfg.context_node_nf;
-    md.fin = md.nf + 1 + md.ctx;
-    md.n_layers = m->cfg.n_layers;
-    md.norm_constant = m->cfg.norm_constant;
-    return md;
 }
 
 int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,

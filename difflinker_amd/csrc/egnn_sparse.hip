@@ -1,0 +1,504 @@
+// egnn_sparse.hip — MI355X (gfx950) kernels for DiffLinker's pocket-conditioned denoiser
+// (reference DynamicsWithPockets.forward, src/egnn.py:470-552; radius graph :554-596; EGNN :218-238 with
+// edge_mask=None).  Molecules here have N ~ 300 atoms (fragments + pocket + linker) and a SPARSE edge set
+// (ligand-ligand fully connected, pocket-pocket <= 4 A, ligand-pocket <= 10 A, no self loops), so the
+// LDS-resident one-workgroup-per-molecule design of egnn_fc.hip does not apply.  Structure:
+//   * node features h, the first-layer projections P,Q and the coordinates live in a caller-provided HBM
+//     workspace (L2/MALL-resident: 19 k atoms x 128 fp32 = 9.6 MB each at the C4 config);
+//   * the radius graph is rebuilt on the GPU every forward (count -> scan -> fill), one wave per atom; each
+//     atom's neighbour list is padded to whole tiles of 32 edges, so a tile belongs to ONE receiving atom;
+//   * the edge pass runs over tiles: first layer generated as MFMA A-fragments from gathered P_i, Q_j rows,
+//     second layer [32x128]x[128x128] on v_mfma_f32_32x32x2_f32 with the weights in LDS, SiLU, and the sum
+//     over the tile's edges reduced IN REGISTERS to one partial row per tile (no atomics: the node kernel
+//     adds an atom's tile partials in tile order, so the result is deterministic);
+//   * the node MLP (+ the next pass's projections) is one kernel per pass over 32-atom row tiles.
+// Arithmetic: exact fp32 MFMA (dl_config.precision must be DL_PRECISION_FP32 for this path in round 1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pack_layout.h"
+
+namespace {
+
+constexpr int LDT = 132;                 // LDS row stride of a [32][128] fp32 tile (conflict-free ds_read_b128)
+constexpr int NODE_THREADS = 256;
+constexpr int EDGE_THREADS = 256;
+
+struct PkDims {
+    int B, N, V;                         // V = B*N padded atoms
+    int nf, ctx, fin, D;
+    int graph_type;                      // 0: '4A', 1: 'FC-4A', 2: 'FC-10A-4A'
+    float norm_constant;
+};
+
+// workspace carve-up (all offsets in bytes, 256-B aligned)
+struct PkWs {
+    float *H, *P, *Q, *X, *X0, *partial, *partialx;
+    int *flags, *ntile, *tile_off, *tile_row, *col, *total;
+    size_t bytes;
+};
+
+__host__ __device__ inline size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline PkWs carve(void* base, int B, int N) {
+    const size_t V = size_t(B) * N;
+    const size_t TMAX = V * N / 32 + V + 1;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += al256(bytes); return r; };
+    PkWs w;
+    w.H = reinterpret_cast<float*>(take(V * HID * 4));
+    w.P = reinterpret_cast<float*>(take(V * HID * 4));
+    w.Q = reinterpret_cast<float*>(take(V * HID * 4));
+    w.X = reinterpret_cast<float*>(take(V * 16));
+    w.X0 = reinterpret_cast<float*>(take(V * 16));
+    w.flags = reinterpret_cast<int*>(take(V * 4));
+    w.ntile = reinterpret_cast<int*>(take(V * 4));
+    w.tile_off = reinterpret_cast<int*>(take((V + 1) * 4));
+    w.total = reinterpret_cast<int*>(take(256));
+    w.tile_row = reinterpret_cast<int*>(take(TMAX * 4));
+    w.col = reinterpret_cast<int*>(take(TMAX * 32 * 4));
+    w.partial = reinterpret_cast<float*>(take(TMAX * HID * 4));
+    w.partialx = reinterpret_cast<float*>(take(TMAX * 16));
+    w.bytes = off;
+    return w;
+}
+
+// atom flags
+constexpr int F_REAL = 1, F_LIG = 2, F_POCK = 4;
+
+// ---------------------------------------------------------------------------------------------------
+// 1. per-atom setup: masked coordinates, role flags, embedding h = We*[h_feat, t, ctx] + be
+//    (egnn.py:486-512, :224).  One thread per (atom, feature).
+// ---------------------------------------------------------------------------------------------------
+__global__ void pk_init_kernel(PkDims d, PkWs w, const float* __restrict__ wp, const float* __restrict__ xh,
+                               const float* __restrict__ t, int t_stride, const int8_t* __restrict__ node_mask,
+                               const float* __restrict__ linker_mask, const float* __restrict__ context) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = gid >> 7, f = gid & (HID - 1);
+    if (v >= d.V) return;
+    const int b = v / d.N;
+    const bool real = node_mask[v] != 0;
+    const float nm = real ? 1.0f : 0.0f;
+    const float* z = xh + size_t(v) * d.D;
+    if (f < 4) {
+        const float xv = (f < 3) ? z[f] * nm : 0.0f;
+        w.X[4 * v + f] = xv;
+        w.X0[4 * v + f] = xv;
+    }
+    if (f == 4) {
+        // fragment-only / pocket-only masks are the last two context channels (egnn.py:486-487)
+        const bool lig = real && ((linker_mask[v] != 0.0f) || (context[size_t(v) * d.ctx + d.ctx - 2] != 0.0f));
+        const bool pock = real && (context[size_t(v) * d.ctx + d.ctx - 1] != 0.0f);
+        w.flags[v] = (real ? F_REAL : 0) | (lig ? F_LIG : 0) | (pock ? F_POCK : 0);
+    }
+    float acc = wp[OFF_EMB_B + f];
+    const float* wrow = wp + OFF_EMB_W + f * FINP;
+    for (int k = 0; k < d.fin; ++k) {
+        float hin;
+        if (k < d.nf) hin = z[3 + k] * nm;
+        else if (k == d.nf) hin = t[size_t(b) * t_stride];      // time feature is not masked (egnn.py:501-509)
+        else hin = context[size_t(v) * d.ctx + (k - d.nf - 1)];
+        acc = fmaf(wrow[k], hin, acc);
+    }
+    w.H[size_t(v) * HID + f] = acc;
+}
+
+// edge predicate of get_dist_edges / get_dist_edges_4A (egnn.py:554-596), i != j, same molecule
+__device__ __forceinline__ bool pk_adjacent(int gt, int fi, int fj, float d2) {
+    if (!(fi & F_REAL) || !(fj & F_REAL)) return false;
+    if (gt == 0) return d2 <= 16.0f;
+    const bool li = fi & F_LIG, lj = fj & F_LIG, pi = fi & F_POCK, pj = fj & F_POCK;
+    const float cut2 = (gt == 1) ? 16.0f : 100.0f;
+    return (li && lj) || (pi && pj && d2 <= 16.0f) || (((li && pj) || (pi && lj)) && d2 <= cut2);
+}
+
+// 2./4. one wave per atom: count neighbours (FILL = false) or write the padded neighbour list (FILL = true)
+template <bool FILL>
+__global__ void pk_edges_kernel(PkDims d, PkWs w) {
+    const int lane = threadIdx.x & 63;
+    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (v >= d.V) return;
+    const int b = v / d.N;
+    const int fi = w.flags[v];
+    const float4 xi = *reinterpret_cast<const float4*>(w.X + 4 * v);
+    int count = 0;
+    const int base_tile = FILL ? w.tile_off[v] : 0;
+    for (int j0 = 0; j0 < d.N; j0 += 64) {
+        const int jn = j0 + lane;
+        const int u = b * d.N + jn;
+        bool adj = false;
+        if (jn < d.N && u != v) {
+            const float4 xj = *reinterpret_cast<const float4*>(w.X + 4 * u);
+            const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            adj = pk_adjacent(d.graph_type, fi, w.flags[u], dx * dx + dy * dy + dz * dz);
+        }
+        const unsigned long long bal = __ballot(adj);
+        if (FILL && adj) w.col[size_t(base_tile) * 32 + count + __popcll(bal & ((1ull << lane) - 1ull))] = u;
+        count += __popcll(bal);
+    }
+    const int nt = (count + 31) >> 5;
+    if (!FILL) {
+        if (lane == 0) w.ntile[v] = nt;
+    } else {
+        for (int e = count + lane; e < nt * 32; e += 64) w.col[size_t(base_tile) * 32 + e] = -1;   // padding
+        if (lane < nt) w.tile_row[base_tile + lane] = v;
+        for (int k = 64 + lane; k < nt; k += 64) w.tile_row[base_tile + k] = v;
+    }
+}
+
+// 3. exclusive scan of ntile[0..V) -> tile_off, total tile count (single workgroup)
+__global__ void pk_scan_kernel(int V, const int* __restrict__ ntile, int* __restrict__ tile_off, int* __restrict__ total) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int per = (V + nth - 1) / nth;
+    const int lo = min(tid * per, V), hi = min(lo + per, V);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += ntile[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < nth; off <<= 1) {
+        const int add = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int i = lo; i < hi; ++i) { tile_off[i] = run; run += ntile[i]; }
+    if (tid == nth - 1) { tile_off[V] = part[tid]; total[0] = part[tid]; }
+}
+
+// acc[32 rows x 32 features] += A[rows][k] * W'[feature][k], k = 0..127; A = LDS tile (row stride LDT),
+// this lane supplies k = 64*hh + s; B = pre-loaded fp32 fragments of one unit slice
+__device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int row, int hh, const BFrag& b) {
+    const float4* ap = reinterpret_cast<const float4*>(abuf + row * LDT + 64 * hh);
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) {
+        const float4 a = ap[sg];
+        acc = mfma32(a.x, b.q[sg].x, acc);
+        acc = mfma32(a.y, b.q[sg].y, acc);
+        acc = mfma32(a.z, b.q[sg].z, acc);
+        acc = mfma32(a.w, b.q[sg].w, acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 5. node kernel, one workgroup (4 waves = 4 feature tiles) per 32-atom row tile:
+//    POST: agg = (sum of the atom's tile partials), t = SiLU(W3a' h + W3b' agg + b3'), h += W4' t + b4, masked
+//          (GCL.node_model egnn.py:62-72,78-79);   PRE: P = W1a' h + b1', Q = W1b' h for the NEXT pass.
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NODE_THREADS)
+pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __restrict__ pre_units,
+               const float* __restrict__ pre_bias) {
+    __shared__ __attribute__((aligned(16))) float hL[32 * LDT];
+    __shared__ __attribute__((aligned(16))) float aL[32 * LDT];
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
+    const int row0 = blockIdx.x * 32;
+    // stage h rows (and the aggregate) into LDS
+    for (int e = tid; e < 32 * 32; e += NODE_THREADS) {
+        const int r = e >> 5, q = e & 31;
+        const int v = row0 + r;
+        float4 hv = make_float4(0.f, 0.f, 0.f, 0.f), av = hv;
+        if (v < d.V) {
+            hv = *reinterpret_cast<const float4*>(w.H + size_t(v) * HID + 4 * q);
+            if (post) {
+                const int t0 = w.tile_off[v], nt = w.ntile[v];
+                for (int k = 0; k < nt; ++k) {                      // fixed order: deterministic
+                    const float4 pv = *reinterpret_cast<const float4*>(w.partial + size_t(t0 + k) * HID + 4 * q);
+                    av.x += pv.x; av.y += pv.y; av.z += pv.z; av.w += pv.w;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(hL + r * LDT + 4 * q) = hv;
+        if (post) *reinterpret_cast<float4*>(aL + r * LDT + 4 * q) = av;
+    }
+    __syncthreads();
+    const int nt = wv;                                             // this wave's 32-feature tile
+    if (post) {
+        const float* vecs = post + G_VEC;
+        floatx16 acc = splat16(vecs[4 * HID + 32 * nt + c]);
+        {
+            const BFrag b3a = load_bfrag(post + G_W3A + nt * (UNIT / 4), lane);
+            gemm_lds(acc, hL, c, hh, b3a);
+        }
+        {
+            const BFrag b3b = load_bfrag(post + G_W3B + nt * (UNIT / 4), lane);
+            gemm_lds(acc, aL, c, hh, b3b);
+        }
+        __syncthreads();                                           // all waves done reading aL
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) aL[acc_row(reg, hh) * LDT + 32 * nt + c] = silu_u(acc[reg]);
+        __syncthreads();
+        const float b4 = vecs[5 * HID + 32 * nt + c];
+        floatx16 hn;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) hn[reg] = hL[acc_row(reg, hh) * LDT + 32 * nt + c] + b4;
+        {
+            const BFrag b4f = load_bfrag(post + G_W4 + nt * (UNIT / 4), lane);
+            gemm_lds(hn, aL, c, hh, b4f);
+        }
+        __syncthreads();                                           // all waves done reading hL (residual) and aL
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = acc_row(reg, hh);
+            const int v = row0 + r;
+            const float val = (v < d.V && (w.flags[v] & F_REAL)) ? hn[reg] : 0.0f;   // h * node_mask
+            hL[r * LDT + 32 * nt + c] = val;
+            if (v < d.V) w.H[size_t(v) * HID + 32 * nt + c] = val;
+        }
+        __syncthreads();
+    }
+    if (pre_units) {
+        // P (feature tile nt of W1a') and Q (feature tile nt of W1b') for the next edge pass
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const BFrag bf = load_bfrag(pre_units + which * UNIT + nt * (UNIT / 4), lane);
+            floatx16 acc = splat16(which == 0 ? pre_bias[32 * nt + c] : 0.0f);
+            gemm_lds(acc, hL, c, hh, bf);
+            float* dst = which == 0 ? w.P : w.Q;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int v = row0 + acc_row(reg, hh);
+                if (v < d.V) dst[size_t(v) * HID + 32 * nt + c] = acc[reg];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 6. edge kernel: persistent workgroups (4 waves, second-layer weights in LDS), waves take tiles round-robin.
+//    EQUIV = false: partial[t][f] = sum over the tile's edges of u2[f]            (edge_mask = None: weight 1)
+//    EQUIV = true : partialx[t]   = sum over the tile's edges of cdiff * (w7'.u2)
+// ---------------------------------------------------------------------------------------------------
+template <bool EQUIV>
+__global__ void __launch_bounds__(EDGE_THREADS)
+pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */) {
+    __shared__ __attribute__((aligned(16))) float W[UNIT];
+    __shared__ __attribute__((aligned(16))) float vec[4 * HID];
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
+    {
+        const float4* src = reinterpret_cast<const float4*>(wimg);
+        float4* dst = reinterpret_cast<float4*>(W);
+        for (int e = tid; e < UNIT / 4; e += EDGE_THREADS) dst[e] = src[e];
+        const int nv = EQUIV ? 4 : 3;
+        for (int e = tid; e < nv * HID; e += EDGE_THREADS) vec[e] = vecs[e];
+    }
+    __syncthreads();
+    float bias[4], w7[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        bias[nt] = vec[2 * HID + 32 * nt + c];
+        w7[nt] = EQUIV ? vec[3 * HID + 32 * nt + c] : 0.0f;
+    }
+    const float4* wrp = reinterpret_cast<const float4*>(vec + 64 * hh);
+    const float4* wdp = reinterpret_cast<const float4*>(vec + HID + 64 * hh);
+    const float4* Wp = reinterpret_cast<const float4*>(W) + (64 * hh * 32 + c);
+    const int ntiles = w.total[0];
+    const int gw = blockIdx.x * (EDGE_THREADS / 64) + wv, GW = gridDim.x * (EDGE_THREADS / 64);
+
+    for (int t = gw; t < ntiles; t += GW) {
+        const int i = w.tile_row[t];
+        const int jraw = w.col[size_t(t) * 32 + c];
+        const bool valid = jraw >= 0;
+        const int j = valid ? jraw : i;
+        const int nvalid = __popcll(__ballot(valid)) >> 1;          // both halves hold the same 32 edges
+        const float4 xi = *reinterpret_cast<const float4*>(w.X + 4 * i);
+        const float4 xj = *reinterpret_cast<const float4*>(w.X + 4 * j);
+        const float4 yi = *reinterpret_cast<const float4*>(w.X0 + 4 * i);
+        const float4 yj = *reinterpret_cast<const float4*>(w.X0 + 4 * j);
+        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
+        const float r = dx * dx + dy * dy + dz * dz;
+        const float d0 = ex * ex + ey * ey + ez * ez;
+        float a[64];
+        {
+            const float4* Pp = reinterpret_cast<const float4*>(w.P + size_t(i) * HID + 64 * hh);
+            const float4* Qp = reinterpret_cast<const float4*>(w.Q + size_t(j) * HID + 64 * hh);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
+                a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
+                a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
+                a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
+                a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+            }
+        }
+        floatx16 acc0 = splat16(bias[0]), acc1 = splat16(bias[1]), acc2 = splat16(bias[2]), acc3 = splat16(bias[3]);
+#pragma unroll
+        for (int s = 0; s < 64; ++s) {
+            const float4 b = Wp[s * 32];
+            acc0 = mfma32(a[s], b.x, acc0);
+            acc1 = mfma32(a[s], b.y, acc1);
+            acc2 = mfma32(a[s], b.z, acc2);
+            acc3 = mfma32(a[s], b.w, acc3);
+        }
+        if (!EQUIV) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float m = (acc_row(reg, hh) < nvalid) ? 1.0f : 0.0f;   // padding edges sit at the tile's end
+                s0 = fmaf(m, silu_u(acc0[reg]), s0);
+                s1 = fmaf(m, silu_u(acc1[reg]), s1);
+                s2 = fmaf(m, silu_u(acc2[reg]), s2);
+                s3 = fmaf(m, silu_u(acc3[reg]), s3);
+            }
+            s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+            if (hh == 0) {
+                float* dst = w.partial + size_t(t) * HID + c;
+                dst[0] = s0; dst[32] = s1; dst[64] = s2; dst[96] = s3;
+            }
+        } else {
+            float srow[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float ts = w7[0] * silu_u(acc0[reg]);
+                ts = fmaf(w7[1], silu_u(acc1[reg]), ts);
+                ts = fmaf(w7[2], silu_u(acc2[reg]), ts);
+                ts = fmaf(w7[3], silu_u(acc3[reg]), ts);
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) ts += __shfl_xor(ts, off);
+                srow[reg] = ts;
+            }
+            const int src_lane = 32 * ((c >> 2) & 1);
+            const int my_reg = (c & 3) + 4 * (c >> 3);
+            float s_own = 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const float vv = __shfl(srow[reg], src_lane);
+                s_own = (reg == my_reg) ? vv : s_own;
+            }
+            const float den = sqrtf(r + 1e-8f) + d.norm_constant;   // coord2diff, egnn.py:299-300
+            const float f = (hh == 0 && valid) ? s_own : 0.0f;
+            float ax = (dx / den) * f, ay = (dy / den) * f, az = (dz / den) * f;
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                ax += __shfl_xor(ax, off);
+                ay += __shfl_xor(ay, off);
+                az += __shfl_xor(az, off);
+            }
+            if (lane == 0) *reinterpret_cast<float4*>(w.partialx + size_t(t) * 4) = make_float4(ax, ay, az, 0.0f);
+        }
+    }
+}
+
+// 7. coordinate update x += (sum of the atom's tile partials) * linker_mask, masked (egnn.py:110-124)
+__global__ void pk_xupdate_kernel(PkDims d, PkWs w, const float* __restrict__ linker_mask) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= d.V) return;
+    const int t0 = w.tile_off[v], nt = w.ntile[v];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int k = 0; k < nt; ++k) {
+        const float4 p = *reinterpret_cast<const float4*>(w.partialx + size_t(t0 + k) * 4);
+        ax += p.x; ay += p.y; az += p.z;
+    }
+    const float lm = linker_mask ? linker_mask[v] : 1.0f;
+    const float nm = (w.flags[v] & F_REAL) ? 1.0f : 0.0f;
+    float4 x = *reinterpret_cast<const float4*>(w.X + 4 * v);
+    x.x = (x.x + ax * lm) * nm; x.y = (x.y + ay * lm) * nm; x.z = (x.z + az * lm) * nm;
+    *reinterpret_cast<float4*>(w.X + 4 * v) = x;
+}
+
+// 8. output head: h_final = (Wo h + bo)[:nf] * node_mask, vel = (x - x0) * node_mask, NaN flags per molecule
+__global__ void pk_out_kernel(PkDims d, PkWs w, const float* __restrict__ wp, float* __restrict__ out,
+                              int* __restrict__ nan_flags) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int v = gid / d.D, k = gid - v * d.D;
+    if (v >= d.V) return;
+    const float nm = (w.flags[v] & F_REAL) ? 1.0f : 0.0f;
+    float val;
+    int bit;
+    if (k < 3) {
+        val = (w.X[4 * v + k] - w.X0[4 * v + k]) * nm;
+        bit = 1;
+    } else {
+        const int o = k - 3;
+        const float* hp = w.H + size_t(v) * HID;
+        const float* wo = wp + OFF_OUT_W + o * HID;
+        float acc = wp[OFF_OUT_B + o];
+        for (int q = 0; q < HID; ++q) acc = fmaf(hp[q], wo[q], acc);
+        val = acc * nm;
+        bit = 2;
+    }
+    out[size_t(v) * d.D + k] = val;
+    if (val != val) atomicOr(&nan_flags[v / d.N], bit);
+}
+
+thread_local int g_sparse_last_hip = 0;
+inline bool ok(hipError_t e) {
+    if (e != hipSuccess) { g_sparse_last_hip = int(e); return false; }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dl_pocket_workspace_bytes(int32_t B, int32_t N) {
+    if (B <= 0 || N <= 0) return 0;
+    return carve(nullptr, B, N).bytes;
+}
+
+int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, const float* xh,
+                               const float* t, int32_t t_is_scalar, const int8_t* node_mask,
+                               const float* linker_mask, const float* context, float* out, int32_t* nan_flags,
+                               void* workspace, size_t workspace_bytes, void* stream_) {
+    if (!m || !xh || !t || !node_mask || !linker_mask || !context || !out || !nan_flags || !workspace)
+        return DL_ERR_BAD_ARG;
+    if (B < 0 || N < 1 || graph_type < 0 || graph_type > 2) return DL_ERR_BAD_ARG;
+    if (m->cfg.precision != DL_PRECISION_FP32) return DL_ERR_UNSUPPORTED;       // round 1: exact-fp32 MFMA only
+    if (m->cfg.context_node_nf < 2) return DL_ERR_BAD_ARG;                      // needs the fragment/pocket channels
+    if (B == 0) return DL_OK;
+    if (workspace_bytes < carve(nullptr, B, N).bytes) return DL_ERR_BAD_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream_);
+    const ModelDims md = dims_of(m);
+    PkDims d;
+    d.B = B; d.N = N; d.V = B * N; d.nf = md.nf; d.ctx = md.ctx; d.fin = md.fin; d.D = 3 + md.nf;
+    d.graph_type = graph_type; d.norm_constant = md.norm_constant;
+    const PkWs w = carve(workspace, B, N);
+    const float* wp = m->d_pack;
+    const int V = d.V;
+
+    if (!ok(hipMemsetAsync(nan_flags, 0, size_t(B) * 4, st))) return DL_ERR_HIP;
+    hipLaunchKernelGGL(pk_init_kernel, dim3((V * HID + 255) / 256), dim3(256), 0, st, d, w, wp, xh, t,
+                       t_is_scalar ? 0 : 1, node_mask, linker_mask, context);
+    hipLaunchKernelGGL(pk_edges_kernel<false>, dim3((V + 3) / 4), dim3(256), 0, st, d, w);
+    hipLaunchKernelGGL(pk_scan_kernel, dim3(1), dim3(1024), 0, st, V, w.ntile, w.tile_off, w.total);
+    hipLaunchKernelGGL(pk_edges_kernel<true>, dim3((V + 3) / 4), dim3(256), 0, st, d, w);
+
+    const int row_tiles = (V + 31) / 32;
+    const int edge_grid = 512;                                     // 2 workgroups per CU (64 KB LDS each)
+    for (int blk = 0; blk < md.n_layers; ++blk) {
+        const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
+        const float* g0 = base;
+        const float* g1 = base + GCL_SIZE;
+        const float* eq = base + 2 * GCL_SIZE;
+        // projections for gcl_0 (the previous block's node kernel already produced them, except for block 0)
+        if (blk == 0)
+            hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w,
+                               static_cast<const float*>(nullptr), g0 + G_W1A, g0 + G_VEC);
+        hipLaunchKernelGGL(pk_edge_kernel<false>, dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, g0 + G_W2,
+                           g0 + G_VEC + HID);
+        hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, g0, g1 + G_W1A,
+                           g1 + G_VEC);
+        hipLaunchKernelGGL(pk_edge_kernel<false>, dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, g1 + G_W2,
+                           g1 + G_VEC + HID);
+        hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, g1, eq + E_W5A,
+                           eq + E_VEC);
+        hipLaunchKernelGGL(pk_edge_kernel<true>, dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, eq + E_W6,
+                           eq + E_VEC + HID);
+        hipLaunchKernelGGL(pk_xupdate_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d, w, linker_mask);
+        if (blk + 1 < md.n_layers) {
+            const float* n0 = base + BLOCK_SIZE;                   // next block's gcl_0 projections (h unchanged)
+            hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w,
+                               static_cast<const float*>(nullptr), n0 + G_W1A, n0 + G_VEC);
+        }
+    }
+    hipLaunchKernelGGL(pk_out_kernel, dim3((V * d.D + 255) / 256), dim3(256), 0, st, d, w, wp, out, nan_flags);
+    return ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// pack_layout.h — definitions shared by the kernels' translation units: the packed-weight buffer layout
+// (written by dl_model_create in egnn_fc.hip), the model handle, and a few device helpers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/difflinker_hip.h"
+
+struct dl_model {
+    dl_config cfg;
+    float* d_pack;
+    size_t n_floats;
+};
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int HID = 128;            // hidden_nf
+constexpr int UNIT = HID * HID;     // one packed 128x128 matrix
+constexpr int FINP = 16;            // embedding input width, padded
+constexpr int DMAX = 16;            // row stride of the per-atom state z = [x(3), h(nf)], 3+nf <= 16
+constexpr int CTXMAX = 4;
+
+// ---- packed weight buffer (floats); mirrored by pack_model() below -------------------------------
+constexpr int OFF_EMB_W = 0;                          // [128][FINP]
+constexpr int OFF_EMB_B = OFF_EMB_W + HID * FINP;     // [128]
+constexpr int OFF_OUT_W = OFF_EMB_B + HID;            // [16][128]
+constexpr int OFF_OUT_B = OFF_OUT_W + 16 * HID;       // [16]
+constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
+// GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image), vectors
+constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT;
+constexpr int G_VEC = 6 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
+constexpr int G_SCALE = G_VEC + 6 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max
+constexpr int GCL_SIZE = 6 * UNIT + 6 * HID + 8;
+// equivariant update: units W5a', W5b', W6' (LDS image), vectors
+constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT;
+constexpr int E_VEC = 3 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
+constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max
+constexpr int EQ_SIZE = 3 * UNIT + 5 * HID + 8;
+constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
+
+struct ModelDims {
+    int nf, ctx, fin, n_layers;
+    float norm_constant;
+};
+
+inline ModelDims dims_of(const dl_model* m) {
+    ModelDims md;
+    md.nf = m->cfg.in_node_nf;
+    md.ctx = m->cfg.context_node_nf;
+    md.fin = md.nf + 1 + md.ctx;
+    md.n_layers = m->cfg.n_layers;
+    md.norm_constant = m->cfg.norm_constant;
+    return md;
+}
+
+// u = y * sigmoid(-y / log2e)  ==  -log2(e) * SiLU(pre)  for  y = -log2(e) * pre
+__device__ __forceinline__ float silu_u(float y) {
+    return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
+}
+
+__device__ __forceinline__ floatx16 splat16(float v) {
+    floatx16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = v;
+    return r;
+}
+
+__device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
+__device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// B fragments of one packed unit slice (one 32-feature tile, K = 128): 16 x dwordx4 per lane from L2.
+struct BFrag {
+    float4 q[16];
+};
+__device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, int lane) {
+    BFrag b;
+    const float4* bp = reinterpret_cast<const float4*>(unit_nt) + lane;
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) b.q[sg] = bp[sg * 64];
+    return b;
+}
+
+}  // namespace

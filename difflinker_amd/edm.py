@@ -223,7 +223,7 @@ class EDM(torch.nn.Module):
             assert keep_frames <= self.T
         if not self._fused_ok():
             return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
-                                                keep_frames)
+                                                keep_frames, noise_bank)
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.EDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
@@ -280,24 +280,43 @@ class EDM(torch.nn.Module):
             first = int(st[f != 0].min())
             raise utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
 
-    def _sample_chain_host_loop(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames):
-        """Reference-shaped loop for dynamics the fused kernel does not cover: one HIP denoiser launch and
-        one fused HIP tail per step (edm.py:126-176)."""
+    def _sample_chain_host_loop(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames,
+                                noise_bank=None):
+        """Reference-shaped loop for dynamics the fused kernel does not cover (pockets): one HIP denoiser call
+        and one fused HIP tail per step (edm.py:126-176).  Noise: the reference's ``torch.randn`` call order,
+        or the given bank ``(noise_x [T+2,B,N,3], noise_h [T+2,B,N,nf])``."""
         n_samples, n_nodes = x.size(0), x.size(1)
+        dev = x.device
+        draw_idx = [0]
+
+        def draw():
+            k = draw_idx[0]
+            draw_idx[0] += 1
+            if noise_bank is not None:
+                return torch.cat([noise_bank[0][k].to(dev, torch.float32), noise_bank[1][k].to(dev, torch.float32)], dim=2)
+            return torch.cat([torch.randn((n_samples, n_nodes, self.n_dims), device=dev),
+                              torch.randn((n_samples, n_nodes, self.in_node_nf), device=dev)], dim=2)
+
         x, h = self.normalize(x, h)
         xh = torch.cat([x, h], dim=2)
-        z = self.sample_combined_position_feature_noise(n_samples, n_nodes, mask=linker_mask)
-        z = xh * fragment_mask + z * linker_mask
-        chain = torch.zeros((keep_frames,) + z.size(), device=z.device)
-        for s in reversed(range(0, self.T)):
-            s_array = torch.full((n_samples, 1), fill_value=s, device=z.device)
-            t_array = (s_array + 1) / self.T
-            s_array = s_array / self.T
-            z = self.sample_p_zs_given_zt_only_linker(s=s_array, t=t_array, z_t=z, node_mask=node_mask,
-                                                      fragment_mask=fragment_mask, linker_mask=linker_mask,
-                                                      edge_mask=edge_mask, context=context)
+        z = xh * fragment_mask + (draw() * linker_mask) * linker_mask
+        chain = torch.zeros((keep_frames,) + z.size(), device=dev)
+        coefs, (inv_alpha0, sigma0, sigma_x) = self.step_coefficients(n_samples)
+        for q, s in enumerate(reversed(range(0, self.T))):
+            t_, a_, c_, sg_ = (float(v) for v in coefs[q])
+            t_arr = torch.full((n_samples, 1), t_, device=dev)
+            eps_hat = self.dynamics.forward(xh=z, t=t_arr, node_mask=node_mask, linker_mask=linker_mask,
+                                            context=context, edge_mask=edge_mask)
+            z = self._sampler_step(z, eps_hat, draw(), fragment_mask, linker_mask, _lib.DLStepCoef(t_, a_, c_, sg_))
             chain[(s * keep_frames) // self.T] = self.unnormalize_z(z)
-        x, h = self.sample_p_xh_given_z0_only_linker(z_0=z, node_mask=node_mask, fragment_mask=fragment_mask,
-                                                     linker_mask=linker_mask, edge_mask=edge_mask, context=context)
+        # final decode (edm.py:210-235)
+        zeros = torch.zeros(size=(n_samples, 1), device=dev)
+        eps_hat = self.dynamics.forward(t=zeros, xh=z, node_mask=node_mask, linker_mask=linker_mask,
+                                        edge_mask=edge_mask, context=context) * linker_mask
+        mu_x = inv_alpha0 * (z - sigma0 * eps_hat)
+        xh = mu_x + sigma_x * (draw() * linker_mask)
+        xh = z * fragment_mask + xh * linker_mask
+        x, h = self.unnormalize(xh[:, :, :self.n_dims], xh[:, :, self.n_dims:])
+        h = F.one_hot(torch.argmax(h, dim=2), self.in_node_nf) * node_mask
         chain[0] = torch.cat([x, h], dim=2)
         return chain

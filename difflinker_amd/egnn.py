@@ -287,13 +287,59 @@ class Dynamics(nn.Module):
 
 
 class DynamicsWithPockets(Dynamics):
-    """Pocket-conditioned denoiser on the radius graph (reference egnn.py:470-596).
+    """Pocket-conditioned denoiser on the radius graph.  Reference: ``DynamicsWithPockets`` egnn.py:470-596.
 
-    Row a13 of SURVEY.md section 8 — the sparse-edge HIP kernel is the next scope row; until it lands
-    this class loads checkpoints (same parameters) and fails loudly on ``forward``.
-    """
+    ``edge_mask`` is the per-node batch-index vector ``[B*N]`` of the pockets' ``collate`` (datasets.py:359-364);
+    the last two context channels are the fragment-only / pocket-only masks.  The graph (ligand-ligand fully
+    connected, pocket-pocket <= 4 A, ligand-pocket <= 10 A or 4 A) is rebuilt on the GPU every call and the EGNN
+    runs without an edge mask.  Round 1: exact-fp32 MFMA arithmetic on this path."""
+
+    GRAPH_TYPES = {'4A': 0, 'FC-4A': 1, 'FC-10A-4A': 2}
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.precision = 'fp32'
+        self._workspaces = {}
 
     def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
         assert self.graph_type in ['4A', 'FC-4A', 'FC-10A-4A']
-        raise NotImplementedError('DynamicsWithPockets.forward: radius-graph HIP kernel not built yet '
-                                  '(no PyTorch fallback by design)')
+        lib = _lib.load()
+        dev = xh.device
+        bs, n_nodes = xh.shape[0], xh.shape[1]
+        self.precision = 'fp32'
+        handle = self.hip_model(dev)
+        xh = self._f32(xh)
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)])
+        t = t.to(dev, torch.float32).contiguous().view(-1)
+        t_is_scalar = int(t.numel() == 1)
+        nm = node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous()
+        lm = self._f32(linker_mask.reshape(bs, n_nodes))
+        ctx = self._f32(context.reshape(bs, n_nodes, self.context_node_nf))
+        # frag-only | pocket-only | linker == node_mask, like the reference's assert (egnn.py:488)
+        roles = (ctx[..., -2] != 0) | (ctx[..., -1] != 0) | (lm != 0)
+        assert bool(torch.all(roles == (nm != 0))), 'fragment/pocket/linker masks do not cover node_mask'
+        if edge_mask is not None:
+            want = torch.arange(bs, device=dev, dtype=edge_mask.dtype).repeat_interleave(n_nodes)
+            assert edge_mask.numel() == bs * n_nodes and bool(torch.all(edge_mask.view(-1) == want)), \
+                'edge_mask must be the positional batch-index vector of collate (datasets.py:359-364)'
+        need = int(lib.dl_pocket_workspace_bytes(bs, n_nodes))
+        key = (dev.index, bs, n_nodes)
+        ws = self._workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._workspaces = {key: ws}
+        out = torch.empty_like(xh)
+        flags = torch.empty(bs, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _lib.check(lib.dl_egnn_forward_pocket(
+                handle, bs, n_nodes, self.GRAPH_TYPES[self.graph_type], _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
+                _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(ctx), _lib.ptr(out), _lib.ptr(flags), _lib.ptr(ws), need,
+                ctypes.c_void_p(stream)), 'dl_egnn_forward_pocket')
+        self._raise_on_flags(flags)
+        if self.centering:
+            nm3 = node_mask.reshape(bs, n_nodes, 1).to(out.dtype)
+            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], nm3)
+            out = torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
+        return out

@@ -12,6 +12,8 @@
  *                                           (EGNN.forward :218-238, EquivariantBlock :157-178,
  *                                            GCL :45-80, EquivariantUpdate :101-125,
  *                                            coord2diff :295-301, unsorted_segment_sum :304-320)
+ *   dl_egnn_forward_pocket               <- DynamicsWithPockets.forward       src/egnn.py:470-552
+ *                                           (+ get_dist_edges / get_dist_edges_4A :554-596)
  *   dl_sampler_step                      <- EDM.sample_p_zs_given_zt_only_linker, the part after
  *                                           the denoiser call                   src/edm.py:198-208
  *   dl_sample_chain_fc                   <- EDM.sample_chain                  src/edm.py:126-176
@@ -108,6 +110,22 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
                            const float* xh, const float* t, int32_t t_is_scalar,
                            const int8_t* node_mask, const float* linker_mask, const int8_t* edge_mask,
                            const float* context, float* out, int32_t* nan_flags, void* stream);
+
+/* DynamicsWithPockets.forward (src/egnn.py:470-552): radius graph rebuilt on the GPU every call
+ * (ligand-ligand fully connected, pocket-pocket <= 4 A, ligand-pocket <= 10 A [4 A for 'FC-4A'], everything
+ * <= 4 A for '4A'; no self loops; :554-596), EGNN with edge_mask = None.
+ *   graph_type  0: '4A', 1: 'FC-4A', 2: 'FC-10A-4A'
+ *   linker_mask device f32 [B,N] (required: it defines the ligand atoms together with context[..., -2])
+ *   context     device f32 [B,N,ctx], last two channels = fragment-only / pocket-only masks (:486-487)
+ *   workspace   device scratch of at least dl_pocket_workspace_bytes(B, N) bytes, caller-owned
+ * Molecule membership is positional (atom v belongs to molecule v / N), which is what the reference's batch-index
+ * "edge_mask" vector encodes (src/datasets.py:359-364).  The model must be created with DL_PRECISION_FP32. */
+size_t dl_pocket_workspace_bytes(int32_t B, int32_t N);
+int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t graph_type,
+                               const float* xh, const float* t, int32_t t_is_scalar,
+                               const int8_t* node_mask, const float* linker_mask, const float* context,
+                               float* out, int32_t* nan_flags, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* Per-step scalars of the reverse process, computed by the host exactly as the reference does
  * (src/edm.py:180-185,199,202): one row per reverse step, in execution order (s = T-1 ... 0). */

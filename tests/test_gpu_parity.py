@@ -397,3 +397,74 @@ def test_geom_sized_forward_full_batch():
     out = run_hip_forward(dyn, inp, z, t)
     ev, eh = report('C2 full forward', out, ref, z)
     assert ev <= FWD_TOL and eh <= FWD_TOL
+
+
+# ---------------------------------------------------------------------------------------------------
+# pocket-conditioned path (DynamicsWithPockets, radius graph)
+def make_pocket_dynamics(nf, n_layers, seed, graph_type='FC-10A-4A', coord_gain=0.02):
+    from difflinker_amd import DynamicsWithPockets
+    dyn = DynamicsWithPockets(n_dims=3, in_node_nf=nf, context_node_nf=2, hidden_nf=128, n_layers=n_layers,
+                              norm_constant=1e-6, normalization='batch_norm', graph_type=graph_type)
+    sd = seeded_state_dict(nf + 3, 128, n_layers, seed, coord_gain=coord_gain)
+    dyn.load_state_dict(sd, strict=True)
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=2, n_layers=n_layers, graph_type=graph_type)
+    return dyn.to(dev()), sd, cfg
+
+
+def pocket_inputs(batch, n_frag, n_pocket, linker, nf, seed):
+    from difflinker_amd import synthetic
+    from difflinker_amd.datasets import collate
+    data = collate(synthetic.pocket_molecules(batch, n_frag, n_pocket, linker, nf, seed))
+    inp = synthetic.sampler_inputs(data, pockets=True)
+    B, N = inp['x'].shape[:2]
+    g = torch.Generator().manual_seed(seed + 1)
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.cat([2.0 * torch.randn((B, N, 3), generator=g), torch.randn((B, N, nf), generator=g)], dim=2) * inp['linker_mask']
+    t = torch.rand((B, 1), generator=g)
+    return inp, z, t
+
+
+def test_pocket_forward_vs_reference_golden(golden_dir):
+    g = load_golden(golden_dir, 'pocket_forward')
+    dyn, sd, cfg = make_pocket_dynamics(g['nf'], g['n_layers'], seed=g['weight_seed'], coord_gain=g['coord_gain'])
+    inp = {k: g[k] for k in ('node_mask', 'linker_mask', 'edge_mask', 'context')}
+    out = run_hip_forward(dyn, inp, g['xh'], g['t'])
+    ev, eh = report('golden pocket_forward', out, g['out'], g['xh'])
+    assert ev <= FWD_TOLS['fp32'] and eh <= FWD_TOLS['fp32']
+    nm = g['node_mask'].float()
+    assert float((out * (1 - nm)).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('graph_type', ['FC-10A-4A', 'FC-4A', '4A'])
+def test_pocket_forward_vs_oracle(graph_type):
+    nf = 9
+    dyn, sd, cfg = make_pocket_dynamics(nf, 3, seed=31, graph_type=graph_type)
+    inp, z, t = pocket_inputs(batch=3, n_frag=12, n_pocket=70, linker=(4, 9), nf=nf, seed=33)
+    ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
+                                               inp['context'])
+    out = run_hip_forward(dyn, inp, z, t)
+    ev, eh = report(f'pocket fwd {graph_type}', out, ref, z)
+    assert ev <= FWD_TOLS['fp32'] and eh <= FWD_TOLS['fp32']
+    a = run_hip_forward(dyn, inp, z, t)
+    assert torch.equal(a, out), 'pocket path must be bitwise repeatable'
+
+
+def test_pocket_chain_vs_oracle():
+    """EDM.sample_chain on the pocket path (host-driven loop: HIP denoiser + fused HIP tail per step)."""
+    from difflinker_amd import EDM
+    nf, T = 9, 6
+    dyn, sd, cfg = make_pocket_dynamics(nf, 2, seed=35)
+    inp, _, _ = pocket_inputs(batch=2, n_frag=10, n_pocket=40, linker=(3, 6), nf=nf, seed=37)
+    B, N = inp['x'].shape[:2]
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+              loss_type='l2', norm_values=[1, 4, 10]).to(dev())
+    edm.T = T
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=39)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                            inp['edge_mask'], inp['context'], bank, keep_frames=2)
+    g = {k: v.to(dev()) for k, v in inp.items()}
+    got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
+                           g['context'], keep_frames=2, noise_bank=bank.stacked()).cpu()
+    check_chain('pocket chain T=6', got, want, inp)
