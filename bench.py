@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='C2', choices=['C1', 'C2'])
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4'])
     ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
     ap.add_argument('--T', type=int, default=None, help='reverse steps (default: the config\'s, 500 for C2)')
     ap.add_argument('--uniform-size', action='store_true', help='unpadded variant: every molecule has N atoms')
@@ -49,14 +49,30 @@ def parse():
 
 
 def build_model(cfg, device):
-    from difflinker_amd import Dynamics, EDM
+    from difflinker_amd import Dynamics, DynamicsWithPockets, EDM
     torch.manual_seed(0)                                   # random-init weights of the named architecture
-    dyn = Dynamics(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128,
-                   n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm')
+    cls = Dynamics if cfg['graph_type'] == 'FC' else DynamicsWithPockets
+    dyn = cls(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128,
+              n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm', graph_type=cfg['graph_type'])
     edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2',
               noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
     edm.T = cfg['T']
     return edm.to(device)
+
+
+def pocket_edge_count(inp, cutoff_cross=10.0):
+    """Directed edges of the FC-10A-4A radius graph on the batch's input coordinates (bookkeeping for the
+    algorithmic FLOP count only; egnn.py:565-596)."""
+    x = inp['x']
+    nm = inp['node_mask'].squeeze(-1).bool()
+    lig = (inp['linker_mask'].squeeze(-1).bool() | inp['context'][..., -2].bool()) & nm
+    poc = inp['context'][..., -1].bool() & nm
+    d = torch.cdist(x, x)
+    eye = torch.eye(x.shape[1], dtype=torch.bool).unsqueeze(0)
+    adj = (lig[:, :, None] & lig[:, None, :]) | (poc[:, :, None] & poc[:, None, :] & (d <= 4)) | \
+          (((lig[:, :, None] & poc[:, None, :]) | (poc[:, :, None] & lig[:, None, :])) & (d <= cutoff_cross))
+    adj = adj & nm[:, :, None] & nm[:, None, :] & ~eye
+    return int(adj.sum())
 
 
 def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
@@ -67,23 +83,26 @@ def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
     from oracle import egnn_oracle
     cores = os.cpu_count() or 1
     sd = {k: v.detach().cpu().clone() for k, v in edm.dynamics.state_dict().items()}
-    ocfg = egnn_oracle.EGNNConfig(in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], n_layers=cfg['n_layers'])
+    pockets = cfg['graph_type'] != 'FC'
+    ocfg = egnn_oracle.EGNNConfig(in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], n_layers=cfg['n_layers'],
+                                  graph_type=cfg['graph_type'])
+    forward = egnn_oracle.dynamics_forward_pockets if pockets else egnn_oracle.dynamics_forward
     B, N = inp['x'].shape[:2]
-    b = min(sample_batch, B)
+    b = min(8 if pockets else sample_batch, B)
     g = torch.Generator().manual_seed(1)
     z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
         torch.randn((B, N, 3 + cfg['nf']), generator=g) * inp['linker_mask']
     t = torch.full((b, 1), 0.5)
-    em = inp['edge_mask'].view(B, N * N)[:b].reshape(-1, 1)
+    em = inp['edge_mask'].view(B, N)[:b].reshape(-1) if pockets else inp['edge_mask'].view(B, N * N)[:b].reshape(-1, 1)
     args = (sd, ocfg, t, z[:b], inp['node_mask'][:b], inp['linker_mask'][:b], em, inp['context'][:b])
     best = None
     with torch.no_grad():
         for threads in sorted({min(8, cores), min(16, cores), min(32, cores), min(64, cores)}):
             torch.set_num_threads(threads)
-            egnn_oracle.dynamics_forward(*args)            # warm-up (edge list, allocator)
+            forward(*args)                                 # warm-up (edge list, allocator)
             t0 = time.perf_counter()
             for _ in range(n_forwards):
-                egnn_oracle.dynamics_forward(*args)
+                forward(*args)
             dt = (time.perf_counter() - t0) / n_forwards
             if best is None or dt < best[0]:
                 best = (dt, threads)
@@ -118,12 +137,15 @@ def main():
     data, cfg = synthetic.make_batch(a.config, seed=1000 + rank, batch=a.batch, uniform_size=a.uniform_size)
     if a.T is not None:
         cfg['T'] = a.T
-    inp_cpu = synthetic.sampler_inputs(data)
+    pockets = cfg['graph_type'] != 'FC'
+    inp_cpu = synthetic.sampler_inputs(data, pockets=pockets)
     inp = {k: v.to(device) for k, v in inp_cpu.items()}    # inputs resident in HBM before the timed region
     B, N = inp['x'].shape[:2]
     edm = build_model(cfg, device)
     edm.profile_events = True
     pairs, nodes = synthetic.pair_and_node_counts(data)
+    if pockets:
+        pairs = pocket_edge_count(inp_cpu)
     fin = cfg['nf'] + cfg['ctx'] + 1
     flops_fwd = synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes)
 
@@ -143,7 +165,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_chain()
-        kernel_ms.append(edm.last_kernel_events)
+        kernel_ms.append(getattr(edm, 'last_kernel_events', None))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -152,8 +174,11 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
-    k_ms = [s.elapsed_time(e) for s, e in kernel_ms]
-    k_avg_ms = sum(k_ms) / len(k_ms)
+    if kernel_ms[0] is not None:
+        k_ms = [s.elapsed_time(e) for s, e in kernel_ms]
+        k_avg_ms = sum(k_ms) / len(k_ms)
+    else:                                                  # pocket path: many launches per chain
+        k_avg_ms = 1e3 * elapsed / a.steps
 
     if rank == 0:
         achieved = flops_fwd * (cfg['T'] + 1) / (k_avg_ms * 1e-3) / 1e12
@@ -173,9 +198,9 @@ def main():
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic',
-            'config': {'workload': f'{a.config}: GEOM geom_difflinker hparams (egnn_dynamics, hidden 128, '
+            'config': {'workload': f'{a.config}: {"GEOM geom_difflinker" if not pockets else "pockets_difflinker_full_no_anchors_fc (FC-10A-4A radius graph)"} hparams (egnn_dynamics, hidden 128, '
                                    f'{cfg["n_layers"]} blocks), batch={B} molecules/GPU padded to N={N} '
-                                   f'(n_b {"= N" if a.uniform_size else "~ U{35..50}"}), T={cfg["T"]} reverse steps '
+                                   f'(n_b {"= N" if a.uniform_size else ("~ U{35..50}" if not pockets else "30 fragment + 250 pocket + 6..12 linker atoms")}), T={cfg["T"]} reverse steps '
                                    f'+ decode = {cfg["T"] + 1} EGNN forwards per step; random-init weights, synthetic '
                                    f'fragment graphs',
                        'global_batch': B * world, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}',
@@ -183,7 +208,7 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': None, 'peak_note': peak_note,
                          'frac_of_fp32_vector_peak': achieved / FP32_MFMA_PEAK_TFLOPS,
-                         'kernel': 'sample_chain_fc_kernel', 'kernel_ms': k_avg_ms,
+                         'kernel': 'sample_chain_fc_kernel' if not pockets else 'all kernels of the chain (pk_edge_kernel dominates)', 'kernel_ms': k_avg_ms,
                          'flops_per_launch': flops_fwd * (cfg['T'] + 1)},
             'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
