@@ -65,7 +65,7 @@ def fc_molecules(batch, n_max, n_lo, linker, nf, seed, uniform_size=False):
     return mols
 
 
-def pocket_molecules(batch, n_frag, n_pocket, linker, nf, seed, min_gap=1e-3):
+def pocket_molecules(batch, n_frag, n_pocket, linker, nf, seed, min_gap=1e-4):
     """Per-molecule dicts for the pocket-conditioned config (C4): ``n_frag`` fragment atoms
     uniform in a 5 A ball, ``n_pocket`` pocket atoms uniform in a 10 A ball, then the linker
     rows.  ``fragment_mask`` covers fragment+pocket atoms like the MOAD data
@@ -75,13 +75,16 @@ def pocket_molecules(batch, n_frag, n_pocket, linker, nf, seed, min_gap=1e-3):
     mols = []
     for b in range(batch):
         n_link = _randint(g, linker[0], linker[1])
-        while True:
-            frag_pos = _ball(g, n_frag, 5.0)
-            pock_pos = _ball(g, n_pocket, 10.0)
-            fixed = torch.cat([frag_pos, pock_pos])
+        fixed = torch.cat([_ball(g, n_frag, 5.0), _ball(g, n_pocket, 10.0)])
+        radius = torch.cat([torch.full((n_frag,), 5.0), torch.full((n_pocket,), 10.0)])
+        for _ in range(1000):                       # re-draw only the atoms of pairs that sit on a cut-off
             d = torch.cdist(fixed.double(), fixed.double())
-            if min(((d - 4.0).abs()).min().item(), ((d - 10.0).abs()).min().item()) > min_gap:
+            bad = ((d - 4.0).abs() < min_gap) | ((d - 10.0).abs() < min_gap)
+            rows = torch.nonzero(bad.any(dim=1)).flatten()
+            if rows.numel() == 0:
                 break
+            for a in rows[::2].tolist() or rows.tolist():
+                fixed[a] = _ball(g, 1, float(radius[a]))[0]
         link_pos = 2.0 * torch.randn((n_link, 3), generator=g)
         n = n_frag + n_pocket + n_link
         pos = torch.cat([fixed, link_pos]).to(const.TORCH_FLOAT)
