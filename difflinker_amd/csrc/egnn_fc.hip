@@ -59,7 +59,8 @@ constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
 constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
-constexpr int L_TOTAL = L_DUMMY + LDH;
+constexpr int L_MSCR = L_DUMMY + LDH;                 // per-wave edge-mask bytes of the current tile [8][32] int8
+constexpr int L_TOTAL = L_MSCR + 64;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -70,6 +71,7 @@ struct Lds {
     int *idx, *misc;
     unsigned* fmax;
     float* dummy;
+    signed char* mscr;
 };
 
 __device__ __forceinline__ Lds lds_view(float* base) {
@@ -80,6 +82,7 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
     v.fmax = reinterpret_cast<unsigned*>(base + L_FMAX);
     v.dummy = base + L_DUMMY;
+    v.mscr = reinterpret_cast<signed char*>(base + L_MSCR);
     return v;
 }
 
@@ -384,32 +387,44 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
         }
         // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
         if (!EQUIV) {
+            // mask values of this lane's 16 rows: the pair lanes publish their int8 mask in a per-wave LDS
+            // strip, every lane reads back 4 words = rows {0-3, 8-11, 16-19, 24-27} + 4*hh (no ds_bpermute)
             float mr[16];
-            int ir[16];
+            {
+                signed char* strip = v.mscr + 32 * w;
+                if (hh == 0) strip[c] = (signed char)m;
+                const int* sw = reinterpret_cast<const int*>(strip) + hh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int word = sw[2 * k];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) mr[4 * k + b] = float((signed char)(word >> (8 * b)));
+                }
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int row = acc_row(reg, hh);
-                mr[reg] = __shfl(m, row);
-                ir[reg] = __shfl(i, row);
                 acc0[reg] = silu_u(acc0[reg]);
                 acc1[reg] = silu_u(acc1[reg]);
                 acc2[reg] = silu_u(acc2[reg]);
                 acc3[reg] = silu_u(acc3[reg]);
             }
+            const int p0 = 32 * t + 4 * hh;
             for (int ii = i_first; ii <= i_last; ++ii) {         // 1-2 atoms per tile when n_b >= 32
+                const int lo = ii * nb - p0;                      // row r belongs to atom ii  <=>  lo <= r' < lo + nb
                 float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
-                    const float wgt = (ir[reg] == ii) ? mr[reg] : 0.0f;
+                    const int rr = (reg & 3) + 8 * (reg >> 2);    // row index minus 4*hh
+                    const float wgt = (unsigned(rr - lo) < unsigned(nb)) ? mr[reg] : 0.0f;
                     s0 = fmaf(wgt, acc0[reg], s0);
                     s1 = fmaf(wgt, acc1[reg], s1);
                     s2 = fmaf(wgt, acc2[reg], s2);
                     s3 = fmaf(wgt, acc3[reg], s3);
                 }
-                s0 += __shfl_xor(s0, 32);
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                s3 += __shfl_xor(s3, 32);
+                s0 = xor32_sum(s0);
+                s1 = xor32_sum(s1);
+                s2 = xor32_sum(s2);
+                s3 = xor32_sum(s3);
                 if (ii == sp.row) {
                     sp.v[0] += s0; sp.v[1] += s1; sp.v[2] += s2; sp.v[3] += s3;
                 } else if (hh == 0) {
@@ -418,42 +433,31 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
                 }
             }
         } else {
-            // s_row = sum_f w7'[f] * u2[row][f]: 4 in-lane terms, then a butterfly over the 32 lanes of the half
-            float srow[16];
+            // s_row = sum_f w7'[f] * u2[row][f]: 4 in-lane terms, then a DPP/permlane sum over the 32 lanes of the half;
+            // lane c owns pair c = row c, whose scalar lives in half (c>>2)&1, register (c&3) + 4*(c>>3)
+            const bool want_hi = ((c >> 2) & 1) != 0;
+            const int my_reg = (c & 3) + 4 * (c >> 3);
+            float s_own = 0.0f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float ts = w7[0] * silu_u(acc0[reg]);
                 ts = fmaf(w7[1], silu_u(acc1[reg]), ts);
                 ts = fmaf(w7[2], silu_u(acc2[reg]), ts);
                 ts = fmaf(w7[3], silu_u(acc3[reg]), ts);
-                ts += __shfl_xor(ts, 16);
-                ts += __shfl_xor(ts, 8);
-                ts += __shfl_xor(ts, 4);
-                ts += __shfl_xor(ts, 2);
-                ts += __shfl_xor(ts, 1);
-                srow[reg] = ts;
-            }
-            // lane c owns pair c = row c: fetch its scalar from the half/register that holds row c
-            const int src_lane = 32 * ((c >> 2) & 1);
-            const int my_reg = (c & 3) + 4 * (c >> 3);
-            float s_own = 0.0f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float vv = __shfl(srow[reg], src_lane);
-                s_own = (reg == my_reg) ? vv : s_own;
+                ts = half32_allsum(ts);
+                float lo, hi;
+                both_halves(ts, lo, hi);
+                s_own = (reg == my_reg) ? (want_hi ? hi : lo) : s_own;
             }
             // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
             const float den = sqrtf(r + 1e-8f) + norm_constant;
             const float f = (hh == 0 && valid) ? s_own * m : 0.0f;
             const float tx = (dx / den) * f, ty = (dy / den) * f, tz = (dz / den) * f;
             for (int ii = i_first; ii <= i_last; ++ii) {
-                float ax = (i == ii) ? tx : 0.0f, ay = (i == ii) ? ty : 0.0f, az = (i == ii) ? tz : 0.0f;
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) {            // fixed-order sum over the 32 pair lanes
-                    ax += __shfl_xor(ax, off);
-                    ay += __shfl_xor(ay, off);
-                    az += __shfl_xor(az, off);
-                }
+                // fixed-order sum over the 32 pair lanes (the upper half contributes zeros)
+                const float ax = half32_allsum((i == ii) ? tx : 0.0f);
+                const float ay = half32_allsum((i == ii) ? ty : 0.0f);
+                const float az = half32_allsum((i == ii) ? tz : 0.0f);
                 if (ii == sp.row) {
                     sp.v[0] += ax; sp.v[1] += ay; sp.v[2] += az;
                 } else if (lane == 0) {

@@ -346,40 +346,31 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 s2 = fmaf(m, silu_u(acc2[reg]), s2);
                 s3 = fmaf(m, silu_u(acc3[reg]), s3);
             }
-            s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32); s3 += __shfl_xor(s3, 32);
+            s0 = xor32_sum(s0); s1 = xor32_sum(s1); s2 = xor32_sum(s2); s3 = xor32_sum(s3);
             if (hh == 0) {
                 float* dst = w.partial + size_t(t) * HID + c;
                 dst[0] = s0; dst[32] = s1; dst[64] = s2; dst[96] = s3;
             }
         } else {
-            float srow[16];
+            const bool want_hi = ((c >> 2) & 1) != 0;
+            const int my_reg = (c & 3) + 4 * (c >> 3);
+            float s_own = 0.0f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 float ts = w7[0] * silu_u(acc0[reg]);
                 ts = fmaf(w7[1], silu_u(acc1[reg]), ts);
                 ts = fmaf(w7[2], silu_u(acc2[reg]), ts);
                 ts = fmaf(w7[3], silu_u(acc3[reg]), ts);
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) ts += __shfl_xor(ts, off);
-                srow[reg] = ts;
-            }
-            const int src_lane = 32 * ((c >> 2) & 1);
-            const int my_reg = (c & 3) + 4 * (c >> 3);
-            float s_own = 0.0f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const float vv = __shfl(srow[reg], src_lane);
-                s_own = (reg == my_reg) ? vv : s_own;
+                ts = half32_allsum(ts);
+                float lo, hi;
+                both_halves(ts, lo, hi);
+                s_own = (reg == my_reg) ? (want_hi ? hi : lo) : s_own;
             }
             const float den = sqrtf(r + 1e-8f) + d.norm_constant;   // coord2diff, egnn.py:299-300
             const float f = (hh == 0 && valid) ? s_own : 0.0f;
-            float ax = (dx / den) * f, ay = (dy / den) * f, az = (dz / den) * f;
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
-                ax += __shfl_xor(ax, off);
-                ay += __shfl_xor(ay, off);
-                az += __shfl_xor(az, off);
-            }
+            const float ax = half32_allsum((dx / den) * f);
+            const float ay = half32_allsum((dy / den) * f);
+            const float az = half32_allsum((dz / den) * f);
             if (lane == 0) *reinterpret_cast<float4*>(w.partialx + size_t(t) * 4) = make_float4(ax, ay, az, 0.0f);
         }
     }

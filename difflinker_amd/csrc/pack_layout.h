@@ -73,6 +73,37 @@ __device__ __forceinline__ floatx16 mfma32(float a, float b, floatx16 c) {
 // row of the 32x32 accumulator tile held in register `reg` by a lane of half `hh`
 __device__ __forceinline__ int acc_row(int reg, int hh) { return (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
 
+// ---- cross-lane sums without the LDS crossbar (ds_bpermute costs ~24 cycles per wave instruction; these are VALU ops)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// every lane gets the sum over its 16-lane row: quad_perm xor1, xor2, row_half_mirror, row_mirror (fused v_add_f32_dpp)
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+// every lane gets the sum over its 32-lane half (gfx950 v_permlane16_swap exchanges the two rows of a half)
+__device__ __forceinline__ float half32_allsum(float v) {
+    v = row16_allsum(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// value of lane (l & 31) and of lane 32 + (l & 31), in every lane (v_permlane32_swap)
+__device__ __forceinline__ void both_halves(float v, float& lo, float& hi) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    float lo, hi;
+    both_halves(v, lo, hi);
+    return lo + hi;
+}
+
 // B fragments of one packed unit slice (one 32-feature tile, K = 128): 16 x dwordx4 per lane from L2.
 struct BFrag {
     float4 q[16];
