@@ -113,37 +113,6 @@ __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
 // (host, dl_model_create); dynamic per pass for the activations from a magnitude bound kept in LDS.
 // Unlike the f32-input MFMA - which runs at the fp32 VECTOR rate and did not overlap with this kernel's VALU
 // work - the fp16 MFMA is 16x faster, so the edge pass becomes VALU-bound (SiLU + the splits).
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-
-// 8 consecutive-k fp32 values (already scaled) -> MFMA fragments (8 fp16 = 4 VGPRs) of the hi and lo parts.
-// v_cvt_pkrtz_f16_f32 truncates, so lo = x - hi is exact and has the sign of x.
-__device__ __forceinline__ void split8(const float (&u)[8], uint4& hi, uint4& lo) {
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const auto hp = __builtin_amdgcn_cvt_pkrtz(u[2 * q], u[2 * q + 1]);
-        const float h0 = float(hp[0]), h1 = float(hp[1]);
-        const auto lp = __builtin_amdgcn_cvt_pkrtz(u[2 * q] - h0, u[2 * q + 1] - h1);
-        h[q] = __builtin_bit_cast(unsigned, hp);
-        l[q] = __builtin_bit_cast(unsigned, lp);
-    }
-    hi = make_uint4(h[0], h[1], h[2], h[3]);
-    lo = make_uint4(l[0], l[1], l[2], l[3]);
-}
-
-__device__ __forceinline__ floatx16 mfma_h(const uint4& a, const uint4& b, floatx16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
-}
-
-// largest power of two s with bound * s < 2^15 (fp16 max 65504); 1 for inf/NaN bounds, clamped to 2^+-60
-__device__ __forceinline__ float scale_for(float bound) {
-    const int ex = int((__float_as_uint(bound) >> 23) & 0xffu);     // bound < 2^(ex - 126)
-    int f = 268 - ex;                                               // biased exponent of 2^(15 - (ex - 126))
-    f = min(max(f, 67), 187);
-    if (ex == 255) f = 127;
-    return __uint_as_float(unsigned(f) << 23);
-}
-
 // workgroup-wide max of non-negative floats into an LDS slot (slot zeroed earlier; read after a barrier)
 __device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
     unsigned b = __float_as_uint(val);
@@ -499,8 +468,6 @@ __device__ __forceinline__ void spill_reduce(const Lds& v, int tid, bool equiv) 
     }
 }
 
-// exact reciprocal of a power of two
-__device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
 
 // f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
 constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, FM_X02 = 6;

@@ -12,7 +12,8 @@
 //     over the tile's edges reduced IN REGISTERS to one partial row per tile (no atomics: the node kernel
 //     adds an atom's tile partials in tile order, so the result is deterministic);
 //   * the node MLP (+ the next pass's projections) is one kernel per pass over 32-atom row tiles.
-// Arithmetic: exact fp32 MFMA (dl_config.precision must be DL_PRECISION_FP32 for this path in round 1).
+// Arithmetic: fp32 MFMA or the f16x3 split scheme of egnn_fc.hip (template PREC); on this path the fp16 scales are
+// local: every node-kernel workgroup scales its own 32-row tiles, every edge tile is scaled by its own max |u|.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,7 +34,7 @@ struct PkDims {
 
 // workspace carve-up (all offsets in bytes, 256-B aligned)
 struct PkWs {
-    float *H, *P, *Q, *X, *X0, *partial, *partialx;
+    float *H, *P, *Q, *X, *X0, *partial, *partialx, *pmax, *qmax;
     int *flags, *ntile, *tile_off, *tile_row, *col, *total;
     size_t bytes;
 };
@@ -52,6 +53,8 @@ inline PkWs carve(void* base, int B, int N) {
     w.Q = reinterpret_cast<float*>(take(V * HID * 4));
     w.X = reinterpret_cast<float*>(take(V * 16));
     w.X0 = reinterpret_cast<float*>(take(V * 16));
+    w.pmax = reinterpret_cast<float*>(take(V * 4));
+    w.qmax = reinterpret_cast<float*>(take(V * 4));
     w.flags = reinterpret_cast<int*>(take(V * 4));
     w.ntile = reinterpret_cast<int*>(take(V * 4));
     w.tile_off = reinterpret_cast<int*>(take((V + 1) * 4));
@@ -168,18 +171,46 @@ __global__ void pk_scan_kernel(int V, const int* __restrict__ ntile, int* __rest
     if (tid == nth - 1) { tile_off[V] = part[tid]; total[0] = part[tid]; }
 }
 
-// acc[32 rows x 32 features] += A[rows][k] * W'[feature][k], k = 0..127; A = LDS tile (row stride LDT),
-// this lane supplies k = 64*hh + s; B = pre-loaded fp32 fragments of one unit slice
-__device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int row, int hh, const BFrag& b) {
-    const float4* ap = reinterpret_cast<const float4*>(abuf + row * LDT + 64 * hh);
+// acc[32 rows x 32 features] += A[rows][k] * W'[feature][k], k = 0..127; A = LDS tile (row stride LDT), B = pre-loaded
+// fragments of one unit slice.  PREC 0: fp32 MFMA, lane supplies k = 64*hh + s.  PREC 1 (f16x3): lane supplies
+// k = 16*slab + 8*hh + e, A is scaled by `sa` (power of two) and split into fp16 hi+lo (see egnn_fc.hip).
+template <int PREC>
+__device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int row, int hh, const BFrag& b, float sa) {
+    if constexpr (PREC == 0) {
+        const float4* ap = reinterpret_cast<const float4*>(abuf + row * LDT + 64 * hh);
 #pragma unroll
-    for (int sg = 0; sg < 16; ++sg) {
-        const float4 a = ap[sg];
-        acc = mfma32(a.x, b.q[sg].x, acc);
-        acc = mfma32(a.y, b.q[sg].y, acc);
-        acc = mfma32(a.z, b.q[sg].z, acc);
-        acc = mfma32(a.w, b.q[sg].w, acc);
+        for (int sg = 0; sg < 16; ++sg) {
+            const float4 a = ap[sg];
+            acc = mfma32(a.x, b.q[sg].x, acc);
+            acc = mfma32(a.y, b.q[sg].y, acc);
+            acc = mfma32(a.z, b.q[sg].z, acc);
+            acc = mfma32(a.w, b.q[sg].w, acc);
+        }
+    } else {
+        const float* ap = abuf + row * LDT + 8 * hh;
+#pragma unroll
+        for (int slab = 0; slab < 8; ++slab) {
+            const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * slab);
+            const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * slab + 4);
+            const float u[8] = {a0.x * sa, a0.y * sa, a0.z * sa, a0.w * sa, a1.x * sa, a1.y * sa, a1.z * sa, a1.w * sa};
+            uint4 hi, lo;
+            split8(u, hi, lo);
+            const uint4 bh = __builtin_bit_cast(uint4, b.q[slab]), bl = __builtin_bit_cast(uint4, b.q[8 + slab]);
+            acc = mfma_h(lo, bh, acc);
+            acc = mfma_h(hi, bl, acc);
+            acc = mfma_h(hi, bh, acc);
+        }
     }
+}
+
+// max of non-negative floats over the workgroup, via an LDS word (zeroed before, read after a barrier)
+__device__ __forceinline__ void wg_max(unsigned* slot, float val, int lane) {
+    float m = val;
+    m = fmaxf(m, dpp_mov<0xB1>(m));
+    m = fmaxf(m, dpp_mov<0x4E>(m));
+    m = fmaxf(m, dpp_mov<0x141>(m));
+    m = fmaxf(m, dpp_mov<0x140>(m));
+    if ((lane & 15) == 0) atomicMax(slot, __float_as_uint(m));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -187,16 +218,23 @@ __device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int r
 //    POST: agg = (sum of the atom's tile partials), t = SiLU(W3a' h + W3b' agg + b3'), h += W4' t + b4, masked
 //          (GCL.node_model egnn.py:62-72,78-79);   PRE: P = W1a' h + b1', Q = W1b' h for the NEXT pass.
 // ---------------------------------------------------------------------------------------------------
+template <int PREC>
 __global__ void __launch_bounds__(NODE_THREADS)
 pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __restrict__ pre_units,
-               const float* __restrict__ pre_bias) {
+               const float* __restrict__ pre_bias, const float* __restrict__ pre_scale) {
     __shared__ __attribute__((aligned(16))) float hL[32 * LDT];
     __shared__ __attribute__((aligned(16))) float aL[32 * LDT];
+    __shared__ unsigned mx[4];                                    // f16x3: local |h|, |agg|, |t|, |h_new| maxima
+    __shared__ unsigned rowmx[2][32];                             // f16x3: per-row max |P|, |Q| (bounds the edge A-fragments)
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
     const int row0 = blockIdx.x * 32;
+    if (tid < 4) mx[tid] = 0u;
+    if (tid < 64) rowmx[tid >> 5][tid & 31] = 0u;
+    __syncthreads();
     // stage h rows (and the aggregate) into LDS
+    float hmax = 0.0f, amax = 0.0f;
     for (int e = tid; e < 32 * 32; e += NODE_THREADS) {
         const int r = e >> 5, q = e & 31;
         const int v = row0 + r;
@@ -213,33 +251,57 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         }
         *reinterpret_cast<float4*>(hL + r * LDT + 4 * q) = hv;
         if (post) *reinterpret_cast<float4*>(aL + r * LDT + 4 * q) = av;
+        hmax = fmaxf(hmax, fmaxf(fmaxf(fabsf(hv.x), fabsf(hv.y)), fmaxf(fabsf(hv.z), fabsf(hv.w))));
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(av.x), fabsf(av.y)), fmaxf(fabsf(av.z), fabsf(av.w))));
     }
+    if (PREC == 1) { wg_max(&mx[0], hmax, lane); wg_max(&mx[1], amax, lane); }
     __syncthreads();
     const int nt = wv;                                             // this wave's 32-feature tile
+    float s_h = (PREC == 1) ? scale_for(__uint_as_float(mx[0])) : 1.0f;
     if (post) {
         const float* vecs = post + G_VEC;
-        floatx16 acc = splat16(vecs[4 * HID + 32 * nt + c]);
+        const float* sc = post + G_SCALE;
+        const float b3 = vecs[4 * HID + 32 * nt + c];
+        float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
+        if (PREC == 1) {
+            const float S = fminf(s_h * sc[2], scale_for(__uint_as_float(mx[1])) * sc[3]);
+            s1 = S * inv_pow2(sc[2]); s2 = S * inv_pow2(sc[3]); inv = inv_pow2(S);
+        }
+        floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
         {
             const BFrag b3a = load_bfrag(post + G_W3A + nt * (UNIT / 4), lane);
-            gemm_lds(acc, hL, c, hh, b3a);
+            gemm_lds<PREC>(acc, hL, c, hh, b3a, s1);
         }
         {
             const BFrag b3b = load_bfrag(post + G_W3B + nt * (UNIT / 4), lane);
-            gemm_lds(acc, aL, c, hh, b3b);
+            gemm_lds<PREC>(acc, aL, c, hh, b3b, s2);
         }
         __syncthreads();                                           // all waves done reading aL
+        float tmax = 0.0f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) aL[acc_row(reg, hh) * LDT + 32 * nt + c] = silu_u(acc[reg]);
+        for (int reg = 0; reg < 16; ++reg) {
+            const float tv = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, b3));
+            aL[acc_row(reg, hh) * LDT + 32 * nt + c] = tv;
+            tmax = fmaxf(tmax, fabsf(tv));
+        }
+        if (PREC == 1) wg_max(&mx[2], tmax, lane);
         __syncthreads();
         const float b4 = vecs[5 * HID + 32 * nt + c];
+        float s_t = 1.0f, inv4 = 1.0f;
+        if (PREC == 1) { s_t = scale_for(__uint_as_float(mx[2])); inv4 = inv_pow2(s_t * sc[4]); }
         floatx16 hn;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) hn[reg] = hL[acc_row(reg, hh) * LDT + 32 * nt + c] + b4;
+        for (int reg = 0; reg < 16; ++reg) hn[reg] = (PREC == 0) ? hL[acc_row(reg, hh) * LDT + 32 * nt + c] + b4 : 0.0f;
         {
             const BFrag b4f = load_bfrag(post + G_W4 + nt * (UNIT / 4), lane);
-            gemm_lds(hn, aL, c, hh, b4f);
+            gemm_lds<PREC>(hn, aL, c, hh, b4f, s_t);
+        }
+        if (PREC == 1) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) hn[reg] = fmaf(hn[reg], inv4, hL[acc_row(reg, hh) * LDT + 32 * nt + c] + b4);
         }
         __syncthreads();                                           // all waves done reading hL (residual) and aL
+        float nmax = 0.0f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int r = acc_row(reg, hh);
@@ -247,21 +309,44 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
             const float val = (v < d.V && (w.flags[v] & F_REAL)) ? hn[reg] : 0.0f;   // h * node_mask
             hL[r * LDT + 32 * nt + c] = val;
             if (v < d.V) w.H[size_t(v) * HID + 32 * nt + c] = val;
+            nmax = fmaxf(nmax, fabsf(val));
         }
+        if (PREC == 1) wg_max(&mx[3], nmax, lane);
         __syncthreads();
+        if (PREC == 1) s_h = scale_for(__uint_as_float(mx[3]));
     }
     if (pre_units) {
         // P (feature tile nt of W1a') and Q (feature tile nt of W1b') for the next edge pass
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
             const BFrag bf = load_bfrag(pre_units + which * UNIT + nt * (UNIT / 4), lane);
-            floatx16 acc = splat16(which == 0 ? pre_bias[32 * nt + c] : 0.0f);
-            gemm_lds(acc, hL, c, hh, bf);
+            const float bias = which == 0 ? pre_bias[32 * nt + c] : 0.0f;
+            const float inv = (PREC == 1) ? inv_pow2(s_h * pre_scale[which]) : 1.0f;
+            floatx16 acc = splat16(PREC == 0 ? bias : 0.0f);
+            gemm_lds<PREC>(acc, hL, c, hh, bf, s_h);
             float* dst = which == 0 ? w.P : w.Q;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int v = row0 + acc_row(reg, hh);
-                if (v < d.V) dst[size_t(v) * HID + 32 * nt + c] = acc[reg];
+                const int r = acc_row(reg, hh);
+                const int v = row0 + r;
+                const float val = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias);
+                if (v < d.V) dst[size_t(v) * HID + 32 * nt + c] = val;
+                if (PREC == 1) {
+                    // max over this wave's 32 features of row r (lanes of one half), then across the 4 waves in LDS
+                    float m = fabsf(val);
+                    m = fmaxf(m, dpp_mov<0xB1>(m));
+                    m = fmaxf(m, dpp_mov<0x4E>(m));
+                    m = fmaxf(m, dpp_mov<0x141>(m));
+                    m = fmaxf(m, dpp_mov<0x140>(m));
+                    if ((lane & 15) == 0) atomicMax(&rowmx[which][r], __float_as_uint(m));
+                }
+            }
+        }
+        if (PREC == 1) {
+            __syncthreads();
+            if (tid < 64) {
+                const int v = row0 + (tid & 31);
+                if (v < d.V) (tid < 32 ? w.pmax : w.qmax)[v] = __uint_as_float(rowmx[tid >> 5][tid & 31]);
             }
         }
     }
@@ -272,9 +357,10 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
 //    EQUIV = false: partial[t][f] = sum over the tile's edges of u2[f]            (edge_mask = None: weight 1)
 //    EQUIV = true : partialx[t]   = sum over the tile's edges of cdiff * (w7'.u2)
 // ---------------------------------------------------------------------------------------------------
-template <bool EQUIV>
+template <bool EQUIV, int PREC>
 __global__ void __launch_bounds__(EDGE_THREADS)
-pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */) {
+pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */,
+               const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index) {
     __shared__ __attribute__((aligned(16))) float W[UNIT];
     __shared__ __attribute__((aligned(16))) float vec[4 * HID];
     const int tid = threadIdx.x;
@@ -314,27 +400,84 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
         const float r = dx * dx + dy * dy + dz * dz;
         const float d0 = ex * ex + ey * ey + ez * ez;
-        float a[64];
-        {
-            const float4* Pp = reinterpret_cast<const float4*>(w.P + size_t(i) * HID + 64 * hh);
-            const float4* Qp = reinterpret_cast<const float4*>(w.Q + size_t(j) * HID + 64 * hh);
+        floatx16 acc0, acc1, acc2, acc3;
+        if constexpr (PREC == 0) {
+            float a[64];
+            {
+                const float4* Pp = reinterpret_cast<const float4*>(w.P + size_t(i) * HID + 64 * hh);
+                const float4* Qp = reinterpret_cast<const float4*>(w.Q + size_t(j) * HID + 64 * hh);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
-                a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
-                a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
-                a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
-                a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+                for (int q = 0; q < 16; ++q) {
+                    const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
+                    a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
+                    a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
+                    a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
+                    a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+                }
             }
-        }
-        floatx16 acc0 = splat16(bias[0]), acc1 = splat16(bias[1]), acc2 = splat16(bias[2]), acc3 = splat16(bias[3]);
+            acc0 = splat16(bias[0]); acc1 = splat16(bias[1]); acc2 = splat16(bias[2]); acc3 = splat16(bias[3]);
 #pragma unroll
-        for (int s = 0; s < 64; ++s) {
-            const float4 b = Wp[s * 32];
-            acc0 = mfma32(a[s], b.x, acc0);
-            acc1 = mfma32(a[s], b.y, acc1);
-            acc2 = mfma32(a[s], b.z, acc2);
-            acc3 = mfma32(a[s], b.w, acc3);
+            for (int s = 0; s < 64; ++s) {
+                const float4 b = Wp[s * 32];
+                acc0 = mfma32(a[s], b.x, acc0);
+                acc1 = mfma32(a[s], b.y, acc1);
+                acc2 = mfma32(a[s], b.z, acc2);
+                acc3 = mfma32(a[s], b.w, acc3);
+            }
+        } else {
+            // f16x3: |u| <= |y| <= max|P_i| + max|Q_j| + r*max|wr'| + d0*max|wd'|; the tile's largest bound sets the scale
+            float bound = w.pmax[i] + w.qmax[j] + r * sc[6] + d0 * sc[7];
+            bound = fmaxf(bound, dpp_mov<0xB1>(bound));
+            bound = fmaxf(bound, dpp_mov<0x4E>(bound));
+            bound = fmaxf(bound, dpp_mov<0x141>(bound));
+            bound = fmaxf(bound, dpp_mov<0x140>(bound));
+            {
+                const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(bound), __float_as_uint(bound), false, false);
+                bound = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+            }
+            const float sa = scale_for(__builtin_amdgcn_readfirstlane(bound));   // wave-uniform (both halves hold the same pairs)
+            const float accs = sa * sc[sw_index], inv = inv_pow2(accs);
+            acc0 = splat16(bias[0] * accs); acc1 = splat16(bias[1] * accs);
+            acc2 = splat16(bias[2] * accs); acc3 = splat16(bias[3] * accs);
+            const uint4* Wq = reinterpret_cast<const uint4*>(W) + lane;
+            const float* Pp = w.P + size_t(i) * HID + 8 * hh;
+            const float* Qp = w.Q + size_t(j) * HID + 8 * hh;
+            const float* wrb = vec + 8 * hh;
+            const float* wdb = vec + HID + 8 * hh;
+#pragma unroll
+            for (int slab = 0; slab < 8; ++slab) {
+                float us[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int k0 = 16 * slab + 4 * q;
+                    const float4 P = *reinterpret_cast<const float4*>(Pp + k0);
+                    const float4 Q = *reinterpret_cast<const float4*>(Qp + k0);
+                    const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
+                    const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
+                    us[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x))) * sa;
+                    us[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y))) * sa;
+                    us[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z))) * sa;
+                    us[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w))) * sa;
+                }
+                uint4 ah, al;
+                split8(us, ah, al);
+                uint4 bh[4], bl[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bh[nt] = Wq[(slab * 4 + nt) * 64];
+                    bl[nt] = Wq[((8 + slab) * 4 + nt) * 64];
+                }
+                acc0 = mfma_h(al, bh[0], acc0); acc1 = mfma_h(al, bh[1], acc1);
+                acc2 = mfma_h(al, bh[2], acc2); acc3 = mfma_h(al, bh[3], acc3);
+                acc0 = mfma_h(ah, bl[0], acc0); acc1 = mfma_h(ah, bl[1], acc1);
+                acc2 = mfma_h(ah, bl[2], acc2); acc3 = mfma_h(ah, bl[3], acc3);
+                acc0 = mfma_h(ah, bh[0], acc0); acc1 = mfma_h(ah, bh[1], acc1);
+                acc2 = mfma_h(ah, bh[2], acc2); acc3 = mfma_h(ah, bh[3], acc3);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                acc0[reg] *= inv; acc1[reg] *= inv; acc2[reg] *= inv; acc3[reg] *= inv;
+            }
         }
         if (!EQUIV) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -440,7 +583,6 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
     if (!m || !xh || !t || !node_mask || !linker_mask || !context || !out || !nan_flags || !workspace)
         return DL_ERR_BAD_ARG;
     if (B < 0 || N < 1 || graph_type < 0 || graph_type > 2) return DL_ERR_BAD_ARG;
-    if (m->cfg.precision != DL_PRECISION_FP32) return DL_ERR_UNSUPPORTED;       // round 1: exact-fp32 MFMA only
     if (m->cfg.context_node_nf < 2) return DL_ERR_BAD_ARG;                      // needs the fragment/pocket channels
     if (B == 0) return DL_OK;
     if (workspace_bytes < carve(nullptr, B, N).bytes) return DL_ERR_BAD_ARG;
@@ -462,30 +604,36 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
 
     const int row_tiles = (V + 31) / 32;
     const int edge_grid = 512;                                     // 2 workgroups per CU (64 KB LDS each)
+    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
+    auto node = [&](const float* post, const float* pre_units, const float* pre_bias, const float* pre_scale) {
+        if (f16) hipLaunchKernelGGL(pk_node_kernel<1>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
+        else hipLaunchKernelGGL(pk_node_kernel<0>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
+    };
+    auto edge = [&](bool equiv, const float* wimg, const float* vecs, const float* sc, int sw) {
+        if (!equiv) {
+            if (f16) hipLaunchKernelGGL((pk_edge_kernel<false, 1>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else hipLaunchKernelGGL((pk_edge_kernel<false, 0>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+        } else {
+            if (f16) hipLaunchKernelGGL((pk_edge_kernel<true, 1>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else hipLaunchKernelGGL((pk_edge_kernel<true, 0>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+        }
+    };
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
         const float* g0 = base;
         const float* g1 = base + GCL_SIZE;
         const float* eq = base + 2 * GCL_SIZE;
         // projections for gcl_0 (the previous block's node kernel already produced them, except for block 0)
-        if (blk == 0)
-            hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w,
-                               static_cast<const float*>(nullptr), g0 + G_W1A, g0 + G_VEC);
-        hipLaunchKernelGGL(pk_edge_kernel<false>, dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, g0 + G_W2,
-                           g0 + G_VEC + HID);
-        hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, g0, g1 + G_W1A,
-                           g1 + G_VEC);
-        hipLaunchKernelGGL(pk_edge_kernel<false>, dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, g1 + G_W2,
-                           g1 + G_VEC + HID);
-        hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, g1, eq + E_W5A,
-                           eq + E_VEC);
-        hipLaunchKernelGGL(pk_edge_kernel<true>, dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, eq + E_W6,
-                           eq + E_VEC + HID);
+        if (blk == 0) node(nullptr, g0 + G_W1A, g0 + G_VEC, g0 + G_SCALE);
+        edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5);
+        node(g0, g1 + G_W1A, g1 + G_VEC, g1 + G_SCALE);
+        edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5);
+        node(g1, eq + E_W5A, eq + E_VEC, eq + E_SCALE);
+        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2);
         hipLaunchKernelGGL(pk_xupdate_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d, w, linker_mask);
         if (blk + 1 < md.n_layers) {
             const float* n0 = base + BLOCK_SIZE;                   // next block's gcl_0 projections (h unchanged)
-            hipLaunchKernelGGL(pk_node_kernel, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w,
-                               static_cast<const float*>(nullptr), n0 + G_W1A, n0 + G_VEC);
+            node(nullptr, n0 + G_W1A, n0 + G_VEC, n0 + G_SCALE);
         }
     }
     hipLaunchKernelGGL(pk_out_kernel, dim3((V * d.D + 255) / 256), dim3(256), 0, st, d, w, wp, out, nan_flags);

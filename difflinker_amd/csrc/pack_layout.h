@@ -104,6 +104,41 @@ __device__ __forceinline__ float xor32_sum(float v) {
     return lo + hi;
 }
 
+// ---- f16x3 split arithmetic (see egnn_fc.hip) ----
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// 8 consecutive-k fp32 values (already scaled) -> MFMA fragments (8 fp16 = 4 VGPRs) of the hi and lo parts.
+// v_cvt_pkrtz_f16_f32 truncates, so lo = x - hi is exact and has the sign of x.
+__device__ __forceinline__ void split8(const float (&u)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const auto hp = __builtin_amdgcn_cvt_pkrtz(u[2 * q], u[2 * q + 1]);
+        const float h0 = float(hp[0]), h1 = float(hp[1]);
+        const auto lp = __builtin_amdgcn_cvt_pkrtz(u[2 * q] - h0, u[2 * q + 1] - h1);
+        h[q] = __builtin_bit_cast(unsigned, hp);
+        l[q] = __builtin_bit_cast(unsigned, lp);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+__device__ __forceinline__ floatx16 mfma_h(const uint4& a, const uint4& b, floatx16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+
+// largest power of two s with bound * s < 2^15 (fp16 max 65504); 1 for inf/NaN bounds, clamped to 2^+-60
+__device__ __forceinline__ float scale_for(float bound) {
+    const int ex = int((__float_as_uint(bound) >> 23) & 0xffu);     // bound < 2^(ex - 126)
+    int f = 268 - ex;                                               // biased exponent of 2^(15 - (ex - 126))
+    f = min(max(f, 67), 187);
+    if (ex == 255) f = 127;
+    return __uint_as_float(unsigned(f) << 23);
+}
+
+// exact reciprocal of a power of two
+__device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
+
 // B fragments of one packed unit slice (one 32-feature tile, K = 128): 16 x dwordx4 per lane from L2.
 struct BFrag {
     float4 q[16];

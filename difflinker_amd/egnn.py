@@ -292,13 +292,12 @@ class DynamicsWithPockets(Dynamics):
     ``edge_mask`` is the per-node batch-index vector ``[B*N]`` of the pockets' ``collate`` (datasets.py:359-364);
     the last two context channels are the fragment-only / pocket-only masks.  The graph (ligand-ligand fully
     connected, pocket-pocket <= 4 A, ligand-pocket <= 10 A or 4 A) is rebuilt on the GPU every call and the EGNN
-    runs without an edge mask.  Round 1: exact-fp32 MFMA arithmetic on this path."""
+    runs without an edge mask.  Same arithmetic modes as ``Dynamics`` (``precision`` = 'f16x3' | 'fp32')."""
 
     GRAPH_TYPES = {'4A': 0, 'FC-4A': 1, 'FC-10A-4A': 2}
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.precision = 'fp32'
         self._workspaces = {}
 
     def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
@@ -306,7 +305,6 @@ class DynamicsWithPockets(Dynamics):
         lib = _lib.load()
         dev = xh.device
         bs, n_nodes = xh.shape[0], xh.shape[1]
-        self.precision = 'fp32'
         handle = self.hip_model(dev)
         xh = self._f32(xh)
         if not torch.is_tensor(t):

@@ -401,12 +401,14 @@ def test_geom_sized_forward_full_batch():
 
 # ---------------------------------------------------------------------------------------------------
 # pocket-conditioned path (DynamicsWithPockets, radius graph)
-def make_pocket_dynamics(nf, n_layers, seed, graph_type='FC-10A-4A', coord_gain=0.02):
+def make_pocket_dynamics(nf, n_layers, seed, graph_type='FC-10A-4A', coord_gain=0.02, precision=None):
     from difflinker_amd import DynamicsWithPockets
     dyn = DynamicsWithPockets(n_dims=3, in_node_nf=nf, context_node_nf=2, hidden_nf=128, n_layers=n_layers,
                               norm_constant=1e-6, normalization='batch_norm', graph_type=graph_type)
     sd = seeded_state_dict(nf + 3, 128, n_layers, seed, coord_gain=coord_gain)
     dyn.load_state_dict(sd, strict=True)
+    if precision is not None:
+        dyn.precision = precision
     cfg = EGNNConfig(in_node_nf=nf, context_node_nf=2, n_layers=n_layers, graph_type=graph_type)
     return dyn.to(dev()), sd, cfg
 
@@ -424,27 +426,30 @@ def pocket_inputs(batch, n_frag, n_pocket, linker, nf, seed):
     return inp, z, t
 
 
-def test_pocket_forward_vs_reference_golden(golden_dir):
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+def test_pocket_forward_vs_reference_golden(golden_dir, precision):
     g = load_golden(golden_dir, 'pocket_forward')
-    dyn, sd, cfg = make_pocket_dynamics(g['nf'], g['n_layers'], seed=g['weight_seed'], coord_gain=g['coord_gain'])
+    dyn, sd, cfg = make_pocket_dynamics(g['nf'], g['n_layers'], seed=g['weight_seed'], coord_gain=g['coord_gain'],
+                                        precision=precision)
     inp = {k: g[k] for k in ('node_mask', 'linker_mask', 'edge_mask', 'context')}
     out = run_hip_forward(dyn, inp, g['xh'], g['t'])
-    ev, eh = report('golden pocket_forward', out, g['out'], g['xh'])
-    assert ev <= FWD_TOLS['fp32'] and eh <= FWD_TOLS['fp32']
+    ev, eh = report(f'golden pocket_forward {precision}', out, g['out'], g['xh'])
+    assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
     nm = g['node_mask'].float()
     assert float((out * (1 - nm)).abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
 @pytest.mark.parametrize('graph_type', ['FC-10A-4A', 'FC-4A', '4A'])
-def test_pocket_forward_vs_oracle(graph_type):
+def test_pocket_forward_vs_oracle(graph_type, precision):
     nf = 9
-    dyn, sd, cfg = make_pocket_dynamics(nf, 3, seed=31, graph_type=graph_type)
+    dyn, sd, cfg = make_pocket_dynamics(nf, 3, seed=31, graph_type=graph_type, precision=precision)
     inp, z, t = pocket_inputs(batch=3, n_frag=12, n_pocket=70, linker=(4, 9), nf=nf, seed=33)
     ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
                                                inp['context'])
     out = run_hip_forward(dyn, inp, z, t)
-    ev, eh = report(f'pocket fwd {graph_type}', out, ref, z)
-    assert ev <= FWD_TOLS['fp32'] and eh <= FWD_TOLS['fp32']
+    ev, eh = report(f'pocket fwd {graph_type} {precision}', out, ref, z)
+    assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
     a = run_hip_forward(dyn, inp, z, t)
     assert torch.equal(a, out), 'pocket path must be bitwise repeatable'
 
