@@ -130,7 +130,12 @@ def main():
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import __graft_entry__ as entry
-    entry.build()
+    if rank == 0:
+        entry.build()                                      # (re)compile once; the other ranks wait for it
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        entry.build()
     from difflinker_amd import synthetic
     from difflinker_amd.distributed import all_gather_frames
 
