@@ -119,7 +119,7 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
  *   context     device f32 [B,N,ctx], last two channels = fragment-only / pocket-only masks (:486-487)
  *   workspace   device scratch of at least dl_pocket_workspace_bytes(B, N) bytes, caller-owned
  * Molecule membership is positional (atom v belongs to molecule v / N), which is what the reference's batch-index
- * "edge_mask" vector encodes (src/datasets.py:359-364).  The model must be created with DL_PRECISION_FP32. */
+ * "edge_mask" vector encodes (src/datasets.py:359-364).  Both precisions are supported. */
 size_t dl_pocket_workspace_bytes(int32_t B, int32_t N);
 int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t graph_type,
                                const float* xh, const float* t, int32_t t_is_scalar,
