@@ -35,12 +35,29 @@ namespace {
 
 constexpr int LDH = 132;            // LDS row stride of [n,128] fp32 tiles: 528 B = 33 x 16 B (conflict-free b128)
 constexpr int NMAX = 55;            // real atoms per molecule that fit the LDS-resident layout
-constexpr int THREADS = 512;
-constexpr int NWAVES = 8;
-#ifndef DL_LOWER_SHARE
-#define DL_LOWER_SHARE 9
+// Workgroup = GWAVES "grid" waves (w < 8: own the 2 x 4 grid of 32x32 output tiles of every per-node GEMM and the
+// matching register tile of h) + optional helper waves (w >= 8) that only take part in the pair passes, where a
+// third wave per SIMD hides the LDS / transcendental / MFMA latencies the first two leave exposed.
+#ifndef DL_THREADS
+#define DL_THREADS 512
 #endif
-constexpr int LOWER_SHARE = DL_LOWER_SHARE;   // of 16: tiles of a SIMD's wave pair given to its older wave (8 = even split)
+constexpr int THREADS = DL_THREADS;
+constexpr int NWAVES = THREADS / 64;
+constexpr int GWAVES = 8;
+constexpr int GTHREADS = 64 * GWAVES;
+__device__ __forceinline__ bool grid_wave(int w) { return NWAVES == GWAVES || w < GWAVES; }
+static_assert(THREADS == 512 || THREADS == 768, "8 grid waves + 0 or 4 helper waves");
+// pair-tile shares of the waves sharing a SIMD (w, w+4[, w+8]), oldest first: the older wave wins the issue
+// arbitration and gets through more tiles per unit time; static, contiguous ranges (deterministic reduction).
+#ifndef DL_SHARE0
+#define DL_SHARE0 (DL_THREADS == 512 ? 9 : 6)
+#endif
+#ifndef DL_SHARE1
+#define DL_SHARE1 (DL_THREADS == 512 ? 7 : 5)
+#endif
+#ifndef DL_SHARE2
+#define DL_SHARE2 (DL_THREADS == 512 ? 0 : 5)
+#endif
 
 // ---- LDS layout (floats) ---------------------------------------------------------------------------
 constexpr int L_A = 0;                                // P  / h row-major / eps (aliased at the end)
@@ -59,8 +76,8 @@ constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
 constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
-constexpr int L_MSCR = L_DUMMY + LDH;                 // per-wave edge-mask bytes of the current tile [8][32] int8
-constexpr int L_TOTAL = L_MSCR + 64;
+constexpr int L_MSCR = L_DUMMY + LDH;                 // per-wave edge-mask bytes of the current tile [NWAVES][32] int8
+constexpr int L_TOTAL = L_MSCR + 8 * NWAVES;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -95,7 +112,7 @@ struct Prof {
     int n;
 };
 __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
-    if (pf.buf != nullptr) {
+    if (pf.buf != nullptr && grid_wave(w)) {
         if (lane == 0 && pf.n < PROF_MAX_EVENTS) {
             unsigned long long* e = pf.buf + (size_t(w) * PROF_MAX_EVENTS + pf.n) * 2;
             e[0] = (unsigned long long)tag;
@@ -155,26 +172,53 @@ __device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int 
     }
 }
 
-// copy the [k][c][nt] image of a 128x128 matrix and `nvec` 128-vectors from L2 into LDS, split into an
-// early load (registers) and a late store so the L2/MALL latency hides under the projections' MFMAs
-struct StageRegs {
-    float4 w[UNIT / 4 / THREADS];
-    float4 vec;
-};
-__device__ __forceinline__ StageRegs stage_load(const float* __restrict__ wimg, const float* __restrict__ vecs,
-                                                int nvec, int tid) {
-    StageRegs r;
+// Workgroup barrier for LDS hand-offs that does NOT drain the vector-memory counter (unlike __syncthreads(), whose
+// fence waits for every LDS-DMA and prefetch in flight): own LDS traffic retired, then s_barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// every global load / LDS-DMA this wave issued has landed (call before the barrier that publishes DMA data)
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// LDS-DMA (global_load_lds_dwordx4: global -> LDS without staging registers, 1 KB per wave instruction) of the
+// [k][c][nt] image of a 128x128 matrix into v.W and of the four 128-vectors at `vecs` into v.vec (a GCL uses three;
+// the fourth slot then receives the next packed vector, unused).  Grid waves only; issued as soon as the previous
+// pair loop has released v.W / v.vec, so the image lands under the node phases.
+__device__ __forceinline__ void stage_dma(const Lds& v, const float* __restrict__ wimg, const float* __restrict__ vecs,
+                                          int w, int tid) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    if (w < 4 * HID / 256)                // wave-uniform; first, so that no wait the compiler adds covers the image
+        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const float4*>(vecs) + tid), (lptr_t)(v.vec + 256 * w),
+                                         16, 0, 0);
     const float4* src = reinterpret_cast<const float4*>(wimg);
 #pragma unroll
-    for (int it = 0; it < UNIT / 4 / THREADS; ++it) r.w[it] = src[it * THREADS + tid];
-    r.vec = (tid < nvec * HID / 4) ? reinterpret_cast<const float4*>(vecs)[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
-    return r;
+    for (int it = 0; it < UNIT / 4 / GTHREADS; ++it)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + it * GTHREADS + tid), (lptr_t)(v.W + 4 * (it * GTHREADS + 64 * w)),
+                                         16, 0, 0);
 }
-__device__ __forceinline__ void stage_store(const Lds& v, const StageRegs& r, int nvec, int tid) {
-    float4* dst = reinterpret_cast<float4*>(v.W);
-#pragma unroll
-    for (int it = 0; it < UNIT / 4 / THREADS; ++it) dst[it * THREADS + tid] = r.w[it];
-    if (tid < nvec * HID / 4) reinterpret_cast<float4*>(v.vec)[tid] = r.vec;
+
+// This wave's projection fragments of a pass, the first thing the pass needs: requested one phase AHEAD (during
+// the previous pass's last node GEMM / the previous coordinate pass's reduction) so the L2/MALL latency is off
+// the critical path.  (The W2' image goes global -> LDS by DMA, stage_dma.)
+struct PreW {
+    BFrag bf;
+};
+__device__ __forceinline__ void load_pre(PreW& pw, const float* __restrict__ unit_a, const float* __restrict__ unit_b,
+                                         int w, int lane) {
+    pw.bf = load_bfrag((w < 4 ? unit_a : unit_b) + (w & 3) * (UNIT / 4), lane);
+}
+// what the NEXT pass needs prefetched (base == nullptr: nothing follows)
+struct NextPass {
+    const float* base;
+    bool equiv;
+};
+__device__ __forceinline__ void load_next(PreW& pw, const NextPass& nx, int w, int lane) {
+    if (nx.base == nullptr) return;
+    if (nx.equiv) load_pre(pw, nx.base + E_W5A, nx.base + E_W5B, w, lane);
+    else load_pre(pw, nx.base + G_W1A, nx.base + G_W1B, w, lane);
+}
+__device__ __forceinline__ void stage_next(const Lds& v, const NextPass& nx, int w, int tid) {
+    if (nx.base == nullptr) return;
+    stage_dma(v, nx.base + (nx.equiv ? E_W6 : G_W2), nx.base + (nx.equiv ? E_VEC : G_VEC) + HID, w, tid);
 }
 
 // store one accumulator element of tile row `row` to a [n][LDH] buffer; rows >= n_b go to the sink row
@@ -227,13 +271,13 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
     const int c = lane & 31, hh = lane >> 5;
     const int npairs = nb * nb;
     const int ntiles = (npairs + 31) >> 5;
-    // Waves w and w+4 share a SIMD and the older one (w < 4) wins the issue arbitration, so it gets through
-    // more tiles per unit time.  Static, contiguous ranges (the deterministic reduction below needs them)
-    // weighted LOWER_SHARE : 16-LOWER_SHARE let both finish closer together (measured: 9:7 is ~1 % faster
-    // than an even split; the SIMD is transcendental-throughput-bound either way).
-    constexpr int SH_LO = LOWER_SHARE, SH_HI = 16 - LOWER_SHARE, SH_TOT = 4 * SH_LO + 4 * SH_HI;   // = 64
-    const int cum0 = (w < 4) ? w * SH_LO : 4 * SH_LO + (w - 4) * SH_HI;
-    const int cum1 = cum0 + ((w < 4) ? SH_LO : SH_HI);
+    // static, contiguous, share-weighted tile ranges in wave order (the deterministic reduction below needs them)
+    constexpr int SH0 = DL_SHARE0, SH1 = DL_SHARE1, SH2 = (NWAVES > 8) ? DL_SHARE2 : 0;
+    constexpr int SH_TOT = 4 * (SH0 + SH1 + SH2);
+    const int grp = w >> 2;
+    const int my_sh = (grp == 0) ? SH0 : (grp == 1) ? SH1 : SH2;
+    const int cum0 = ((grp == 0) ? 0 : (grp == 1) ? 4 * SH0 : 4 * (SH0 + SH1)) + (w & 3) * my_sh;
+    const int cum1 = cum0 + my_sh;
     const int t_begin = (cum0 * ntiles) / SH_TOT, t_end = (cum1 * ntiles) / SH_TOT;
     Spill sp;
     sp.row = (w > 0 && t_begin < t_end) ? (32 * t_begin) / nb : -1;
@@ -241,7 +285,7 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
     float bias[4], w7[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-        bias[nt] = v.vec[2 * HID + 32 * nt + c] * (PREC == 0 ? 1.0f : acc_scale);
+        bias[nt] = v.vec[2 * HID + 32 * nt + c];
         w7[nt] = EQUIV ? v.vec[3 * HID + 32 * nt + c] : 0.0f;
     }
     const float4* wrp = reinterpret_cast<const float4*>(v.vec + 64 * hh);
@@ -267,7 +311,9 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
         float m = 0.0f;
         if (valid) m = emask ? float(emask[v.idx[i] * N + v.idx[j]]) : 1.0f;
 
-        floatx16 acc0 = splat16(bias[0]), acc1 = splat16(bias[1]), acc2 = splat16(bias[2]), acc3 = splat16(bias[3]);
+        // f16x3: the accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
+        floatx16 acc0 = splat16(PREC == 0 ? bias[0] : 0.0f), acc1 = splat16(PREC == 0 ? bias[1] : 0.0f),
+                 acc2 = splat16(PREC == 0 ? bias[2] : 0.0f), acc3 = splat16(PREC == 0 ? bias[3] : 0.0f);
         if constexpr (PREC == 0) {
             // ---- first edge layer, generated as MFMA A-fragments: lane = (pair c, k = 64*hh + s).  Kept as a
             // separate VALU phase (sched_barrier) so the MFMA loop below is a dense matrix-pipe stream that one
@@ -351,7 +397,8 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
             // back to the unscaled pre-activation (exact: inv_scale is a power of two)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                acc0[reg] *= inv_scale; acc1[reg] *= inv_scale; acc2[reg] *= inv_scale; acc3[reg] *= inv_scale;
+                acc0[reg] = fmaf(acc0[reg], inv_scale, bias[0]); acc1[reg] = fmaf(acc1[reg], inv_scale, bias[1]);
+                acc2[reg] = fmaf(acc2[reg], inv_scale, bias[2]); acc3[reg] = fmaf(acc3[reg], inv_scale, bias[3]);
             }
         }
         // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
@@ -483,7 +530,8 @@ __device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restr
 // `par` (f16x3): which of the two h-magnitude slots is current; toggled when h is rewritten.
 template <int PREC>
 __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ g,
-                                         floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf, int& par) {
+                                         floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf, int& par,
+                                         PreW& pw, const NextPass nx) {
     const int c = lane & 31, hh = lane >> 5;
     const int nt = w & 3, mt = w >> 2;
     const float* vecs = g + G_VEC;
@@ -491,46 +539,51 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
     prof_event(pf, w, lane, 10);
     if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; v.fmax[FM_T] = 0u; }
     const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
-    {
-        // first-layer projections P,Q; the 64 KB W2' image streams from L2 underneath them
-        const StageRegs st = stage_load(g + G_W2, vecs + HID, 3, tid);
-        const BFrag bf = load_bfrag(g + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
+    if (grid_wave(w)) {
+        // first-layer projections P,Q (fragments prefetched: `pw`; the W2' image is arriving by DMA)
         const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
-        const float vmax = node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
+        const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
         if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
-        stage_store(v, st, 3, tid);
     }
     prof_event(pf, w, lane, 11);
-    __syncthreads();                       // P, Q, W2', vectors in place; every read of H (v.C) done
+    dma_wait();
+    lds_barrier();                         // P, Q, W2', vectors in place; every read of H (v.C) done
     for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
-    __syncthreads();
+    lds_barrier();
     prof_event(pf, w, lane, 12);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
     const Spill sp = edge_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, accs, inv_pow2(accs));
     prof_event(pf, w, lane, 13);
-    const bool active = (mt == 0) || (nb > 32);
-    __syncthreads();                       // every wave left the edge phase: P (v.A), Q (v.B) dead
+    const bool active = grid_wave(w) && ((mt == 0) || (nb > 32));
+    lds_barrier();                         // every wave left the edge phase: P (v.A), Q (v.B), v.W, v.vec dead
+    if (grid_wave(w)) stage_next(v, nx, w, tid);                   // next pass's W2' image: DMA under the node phases
+    // node-MLP fragments: requested now, they arrive while the aggregate is being completed
+    BFrag b3a, b3b;
+    if (active) {
+        b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
+        b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+    }
     if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
     spill_publish(v, sp, w, lane, false);
-    __syncthreads();
+    lds_barrier();
     spill_reduce(v, tid, false);
-    __syncthreads();                       // aggregate complete in v.C
+    lds_barrier();                         // aggregate complete in v.C
+    if (grid_wave(w)) {
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-        store_row(v, v.A, 32 * mt + acc_row(reg, hh), nb, 32 * nt + c, hown[reg]);
+        for (int reg = 0; reg < 16; ++reg) store_row(v, v.A, 32 * mt + acc_row(reg, hh), nb, 32 * nt + c, hown[reg]);
     }
     if (PREC == 1) {
         float am = 0.0f;
         for (int e = tid; e < nb * HID; e += THREADS) am = fmaxf(am, fabsf(v.C[(e >> 7) * LDH + (e & (HID - 1))]));
         block_max(&v.fmax[FM_AGG], am, lane);
     }
-    __syncthreads();
+    lds_barrier();
     prof_event(pf, w, lane, 14);
     // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
+    BFrag b4f;
     if (active) {
-        const BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
-        const BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+        b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);          // for layer 2, under layer 1's MFMAs
         const float b3 = vecs[4 * HID + 32 * nt + c];
         float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
         if (PREC == 1) {
@@ -553,11 +606,11 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
         if (PREC == 1) block_max(&v.fmax[FM_T], tmax, lane);
     }
     prof_event(pf, w, lane, 15);
-    __syncthreads();
+    lds_barrier();
     // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
+    if (grid_wave(w)) load_next(pw, nx, w, lane);                  // the next pass's projection fragments, under layer 2
     if (active) {
         const float b4 = vecs[5 * HID + 32 * nt + c];
-        const BFrag b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
         float s_t = 1.0f, inv = 1.0f;
         if (PREC == 1) { s_t = scale_for(__uint_as_float(v.fmax[FM_T])); inv = inv_pow2(s_t * sc[4]); }
         floatx16 acc;
@@ -579,42 +632,42 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, int tid, int w, i
     }
     par ^= 1;
     prof_event(pf, w, lane, 16);
-    __syncthreads();
+    lds_barrier();
 }
 
 // EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
 template <int PREC>
 __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w, int lane, const float* __restrict__ e,
                                            const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf,
-                                           int par) {
+                                           int par, PreW& pw, const NextPass nx) {
     const int c = lane & 31;
     const int nt = w & 3;
     const float* vecs = e + E_VEC;
     const float* sc = e + E_SCALE;
     prof_event(pf, w, lane, 30);
-    {
+    if (grid_wave(w)) {
         const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
-        const StageRegs st = stage_load(e + E_W6, vecs + HID, 4, tid);
-        const BFrag bf = load_bfrag(e + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
         const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
-        const float vmax = node_pre<PREC>(v, nb, w, lane, bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
+        const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
         if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
-        stage_store(v, st, 4, tid);
     }
     if (tid < 4 * nb) v.aggx[tid] = 0.0f;
     prof_event(pf, w, lane, 31);
-    __syncthreads();
+    dma_wait();
+    lds_barrier();
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
     const Spill sp = edge_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, accs, inv_pow2(accs));
     prof_event(pf, w, lane, 33);
-    __syncthreads();
+    if (grid_wave(w)) load_next(pw, nx, w, lane);                  // next block's first pass, under the reduction
+    lds_barrier();
+    if (grid_wave(w)) stage_next(v, nx, w, tid);
     spill_publish(v, sp, w, lane, true);
-    __syncthreads();
+    lds_barrier();
     spill_reduce(v, tid, true);
     if (PREC == 1 && tid == 0) { v.fmax[FM_PQ] = 0u; v.fmax[FM_X2] = 0u; }
-    __syncthreads();
+    lds_barrier();
     float n2 = 0.0f;
     if (tid < nb) {
         const float lm = v.lm[tid];
@@ -627,7 +680,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, int tid, int w,
     }
     if (PREC == 1) block_max(&v.fmax[FM_X2], n2, lane);
     prof_event(pf, w, lane, 34);
-    __syncthreads();
+    lds_barrier();
 }
 
 // Dynamics.forward for the molecule resident in LDS: reads v.z (state), v.ctx, v.lm, time feature t;
@@ -644,6 +697,13 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     if (PREC == 1) {
         if (tid < 8) v.fmax[tid] = 0u;
         __syncthreads();
+    }
+
+    PreW pw;
+    if (grid_wave(w)) {                                             // first pass's weights (v.W, v.vec are free here)
+        const NextPass first = {wp + OFF_BLOCKS, false};
+        stage_next(v, first, w, tid);
+        load_next(pw, first, w, lane);
     }
 
     // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
@@ -696,7 +756,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * mt + acc_row(reg, hh);
-        hown[reg] = (row < nb) ? v.C[row * LDH + 32 * nt + c] : 0.0f;
+        hown[reg] = (grid_wave(w) && row < nb) ? v.C[row * LDH + 32 * nt + c] : 0.0f;
     }
     prof_event(pf, w, lane, 2);
 
@@ -704,9 +764,12 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi)
-            gcl_pass<PREC>(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf, par);
-        equiv_pass<PREC>(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par);
+        for (int gi = 0; gi < 2; ++gi) {
+            const NextPass nx = {base + (gi + 1) * GCL_SIZE, gi == 1};
+            gcl_pass<PREC>(v, nb, tid, w, lane, base + gi * GCL_SIZE, hown, emask, N, pf, par, pw, nx);
+        }
+        const NextPass nx = {blk + 1 < md.n_layers ? base + BLOCK_SIZE : nullptr, false};
+        equiv_pass<PREC>(v, nb, tid, w, lane, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par, pw, nx);
     }
     prof_event(pf, w, lane, 3);
 
