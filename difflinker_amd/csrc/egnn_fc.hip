@@ -49,11 +49,12 @@ __device__ __forceinline__ bool grid_wave(int w) { return NWAVES == GWAVES || w 
 static_assert(THREADS == 512 || THREADS == 768, "8 grid waves + 0 or 4 helper waves");
 // pair-tile shares of the waves sharing a SIMD (w, w+4[, w+8]), oldest first: the older wave wins the issue
 // arbitration and gets through more tiles per unit time; static, contiguous ranges (deterministic reduction).
+// Measured (n = 50, ticks per forward): 8:8 4.13 M, 9:7 4.01 M, 10:6 3.94 M, 12:4 4.11 M, one wave only 4.97 M.
 #ifndef DL_SHARE0
-#define DL_SHARE0 (DL_THREADS == 512 ? 9 : 6)
+#define DL_SHARE0 (DL_THREADS == 512 ? 10 : 6)
 #endif
 #ifndef DL_SHARE1
-#define DL_SHARE1 (DL_THREADS == 512 ? 7 : 5)
+#define DL_SHARE1 (DL_THREADS == 512 ? 6 : 5)
 #endif
 #ifndef DL_SHARE2
 #define DL_SHARE2 (DL_THREADS == 512 ? 0 : 5)
