@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIFFLINKER_HIP_LIB') or os.path.join(_HERE, 'libdifflinker_hip.so')
 
 DL_OK = 0
-ABI_VERSION = 2
+ABI_VERSION = 3
 PRECISIONS = {'fp32': 0, 'f16x3': 1}
 DL_ERR_TOO_MANY_ATOMS = -3
 
@@ -26,6 +26,11 @@ class DLConfig(ctypes.Structure):
         ('condition_time', ctypes.c_int32), ('norm_constant', ctypes.c_float),
         ('normalization_factor', ctypes.c_float), ('precision', ctypes.c_int32),
     ]
+
+
+class DLSizeConfig(ctypes.Structure):
+    _fields_ = [('in_node_nf', ctypes.c_int32), ('hidden_nf', ctypes.c_int32), ('out_node_nf', ctypes.c_int32),
+                ('n_layers', ctypes.c_int32)]
 
 
 class DLStepCoef(ctypes.Structure):
@@ -48,7 +53,9 @@ class DLChainArgs(ctypes.Structure):
 
 EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_string', 'dl_model_num_tensors',
            'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
-           'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket')
+           'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
+           'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
+           'dl_size_gnn_forward')
 
 _lib = None
 
@@ -95,6 +102,15 @@ def load():
     lib.dl_egnn_forward_pocket.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dl_sample_chain_fc.restype = i32
     lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
+    lib.dl_size_model_num_tensors.restype = i32
+    lib.dl_size_model_num_tensors.argtypes = [ctypes.POINTER(DLSizeConfig)]
+    lib.dl_size_model_create.restype = i32
+    lib.dl_size_model_create.argtypes = [ctypes.POINTER(DLSizeConfig), ctypes.POINTER(vp), i32, ctypes.POINTER(vp)]
+    lib.dl_size_model_destroy.restype = None
+    lib.dl_size_model_destroy.argtypes = [vp]
+    lib.dl_size_max_fragment_atoms.restype = i32
+    lib.dl_size_gnn_forward.restype = i32
+    lib.dl_size_gnn_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -27,3 +27,9 @@ DATA_ATTRS_TO_ADD_LAST_DIM = {
 
 # linker-size histogram of the ZINC train split (const.py:50-61)
 LINKER_SIZE_DIST = {3: 113928, 4: 85540, 5: 77671, 6: 70946, 7: 30408, 8: 12712, 9: 5177, 10: 1214, 11: 158, 12: 7}
+
+# class tables of the size predictor (const.py:181-206)
+ZINC_TRAIN_LINKER_ID2SIZE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 12]
+ZINC_TRAIN_LINKER_SIZE2ID = {size: idx for idx, size in enumerate(ZINC_TRAIN_LINKER_ID2SIZE)}
+GEOM_TRAIN_LINKER_ID2SIZE = list(range(3, 33)) + [36, 38, 41]
+GEOM_TRAIN_LINKER_SIZE2ID = {size: idx for idx, size in enumerate(GEOM_TRAIN_LINKER_ID2SIZE)}

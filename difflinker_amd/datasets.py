@@ -48,6 +48,42 @@ def collate(batch):
     return out
 
 
+def collate_with_fragment_edges(batch):
+    """``collate`` variant used by the generation scripts and the size predictor (datasets.py:378-422): the edge mask
+    covers FRAGMENT atoms only and an explicit fully-connected edge list ``[rows, cols]`` (e = b*N*N + i*N + j) is
+    attached.  The mask is the float product ``frag_i * frag_j * ~eye`` with ``~eye`` taken on int8, i.e. -1 off the
+    diagonal and -2 ON it (datasets.py:396-399): consumers that call ``.bool()`` on it keep the self loops."""
+    out = {}
+    for data in batch:
+        for key, value in data.items():
+            out.setdefault(key, []).append(value)
+
+    for key, value in out.items():
+        if key in const.DATA_LIST_ATTRS:
+            continue
+        if key in const.DATA_ATTRS_TO_PAD:
+            out[key] = torch.nn.utils.rnn.pad_sequence(value, batch_first=True, padding_value=0)
+            continue
+        raise Exception(f'Unknown batch key: {key}')
+
+    frag_mask = out['fragment_mask']
+    batch_size, n_nodes = frag_mask.size()
+    diag_mask = ~torch.eye(n_nodes, dtype=const.TORCH_INT, device=frag_mask.device).unsqueeze(0)
+    edge_mask = frag_mask[:, None, :] * frag_mask[:, :, None] * diag_mask
+    out['edge_mask'] = edge_mask.view(batch_size * n_nodes * n_nodes, 1)
+
+    idx = torch.arange(batch_size * n_nodes * n_nodes, device=frag_mask.device)
+    base = (idx // (n_nodes * n_nodes)) * n_nodes
+    out['edges'] = [base + (idx // n_nodes) % n_nodes, base + idx % n_nodes]
+
+    atom_mask = (out['fragment_mask'].bool() | out['linker_mask'].bool()).to(const.TORCH_INT)
+    out['atom_mask'] = atom_mask[:, :, None]
+    for key in const.DATA_ATTRS_TO_ADD_LAST_DIM:
+        if key in out.keys():
+            out[key] = out[key][:, :, None]
+    return out
+
+
 def create_template(tensor, fragment_size, linker_size, fill=0):
     """Keep the fragment rows, append ``linker_size`` constant rows (datasets.py:476-480)."""
     keep = tensor[:fragment_size]

@@ -40,15 +40,25 @@ def _mlp(sizes, activation, last_activation):
 
 class GCL(_ParamOnly):
     """Edge MLP (2*nf+edges_in_d -> hidden -> hidden, activation after both) and node MLP
-    (hidden+nf -> hidden -> nf).  Parameters of reference ``GCL`` (egnn.py:10-43)."""
+    (hidden+nf -> hidden -> nf; with ``normalization='batch_norm'`` a BatchNorm1d after each Linear, the layout
+    the size predictor may use).  Parameters of reference ``GCL`` (egnn.py:10-43)."""
 
     def __init__(self, input_nf, output_nf, hidden_nf, normalization_factor, aggregation_method, activation,
-                 edges_in_d=0):
+                 edges_in_d=0, nodes_att_dim=0, attention=False, normalization=None):
         super().__init__()
+        if attention or nodes_att_dim:
+            raise NotImplementedError('attention / node attributes are outside the HIP path')
         self.normalization_factor = normalization_factor
         self.aggregation_method = aggregation_method
+        self.attention = attention
         self.edge_mlp = _mlp([2 * input_nf + edges_in_d, hidden_nf, hidden_nf], activation, last_activation=True)
-        self.node_mlp = _mlp([hidden_nf + input_nf, hidden_nf, output_nf], activation, last_activation=False)
+        if normalization is None:
+            self.node_mlp = _mlp([hidden_nf + input_nf, hidden_nf, output_nf], activation, last_activation=False)
+        elif normalization == 'batch_norm':
+            self.node_mlp = nn.Sequential(nn.Linear(hidden_nf + input_nf, hidden_nf), nn.BatchNorm1d(hidden_nf),
+                                          activation, nn.Linear(hidden_nf, output_nf), nn.BatchNorm1d(output_nf))
+        else:
+            raise NotImplementedError(normalization)
 
 
 class EquivariantUpdate(_ParamOnly):

@@ -19,6 +19,11 @@
  *   dl_sample_chain_fc                   <- EDM.sample_chain                  src/edm.py:126-176
  *                                           (+ :178-208 reverse step, :210-242 final decode,
  *                                            :328-361 noise / (un)normalisation)
+ *   dl_size_model_create / dl_size_gnn_forward
+ *                                        <- SizeGNN (src/linker_size.py:45-91) as driven by
+ *                                           SizeClassifier.forward at inference
+ *                                           (src/linker_size_lightning.py:83-110): the `sample_fn`
+ *                                           of generate.py:86-99 that runs once before a chain
  *
  * Conventions
  *   - every pointer marked "device" is a HIP device pointer owned by the caller (PyTorch-ROCm
@@ -40,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 2
+#define DL_ABI_VERSION 3
 
 typedef enum dl_status {
     DL_OK = 0,
@@ -170,6 +175,48 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* s
  * first workgroup of the next launches logs (phase tag, shader clock) pairs of its first forward. */
 void dl_set_profile_buffer(void* device_buf);
 int32_t dl_profile_max_events(void);
+
+/* ---- linker-size predictor -------------------------------------------------------------------------
+ * SizeGNN hyper-parameters (src/linker_size.py:46); hidden_nf must be 128.  nn.BatchNorm1d
+ * (normalization='batch_norm') is an affine map in eval mode: the caller folds it into the adjacent
+ * Linear before handing the tensors over. */
+typedef struct dl_size_config {
+    int32_t in_node_nf;
+    int32_t hidden_nf;
+    int32_t out_node_nf;
+    int32_t n_layers;
+} dl_size_config;
+
+typedef struct dl_size_model dl_size_model;
+
+/* tensors (host fp32, nn.Linear [out,in] row-major), 4 + 8 * n_layers of them:
+ *   embedding_in.weight, .bias,
+ *   per GCL (gcl1, gcl_layers.0, ...): edge_mlp.0.weight [128,257], .bias, edge_mlp.2.weight, .bias,
+ *                                      node_mlp.0.weight [128,256], .bias, node_mlp.<last>.weight, .bias,
+ *   embedding_out.weight [out,128], .bias */
+int32_t dl_size_model_num_tensors(const dl_size_config* cfg);
+int32_t dl_size_model_create(const dl_size_config* cfg, const void* const* tensors, int32_t n_tensors,
+                             dl_size_model** out);
+void dl_size_model_destroy(dl_size_model* m);
+int32_t dl_size_max_fragment_atoms(void);
+
+/* logits[b] = mean over the N padded nodes of embedding_out(GCL^n(embedding_in(one_hot * fragment_mask)))
+ *   one_hot        device f32 [B,N,in_node_nf]
+ *   positions      device f32 [B,N,3]   (may be NULL when `distances` is given)
+ *   fragment_mask  device f32 [B,N]     node mask of the GNN (fragment atoms; 'fragment_only_mask' with pockets)
+ *   edge_mask      device f32 [B,N,N]   e = b*N*N + i*N + j; an edge is kept where edge_mask != 0 and, when
+ *                                       `distances` is NULL, the squared distance |x_i - x_j|^2 < 6
+ *                                       (src/linker_size_lightning.py:106-107: coord2diff returns the SQUARED
+ *                                       distance and that is what is compared with 6 and fed to the edge MLP)
+ *   distances      device f32 [B,N,N] or NULL: precomputed edge attribute (SizeGNN.forward's own signature,
+ *                                       src/linker_size.py:83); edge_mask is then taken as final
+ *   logits         device f32 [B,out_node_nf]
+ *   flags          device int32 [B]     bit0: NaN in the logits, bit2: more fragment atoms than
+ *                                       dl_size_max_fragment_atoms() */
+int32_t dl_size_gnn_forward(const dl_size_model* m, int32_t B, int32_t N, const float* one_hot,
+                            const float* positions, const float* fragment_mask, const float* edge_mask,
+                            const float* distances, float* logits, int32_t* flags, void* stream);
+
 
 const char* dl_error_string(int32_t status);
 int32_t dl_last_hip_error(void);

@@ -25,7 +25,7 @@ from src.egnn import Dynamics, DynamicsWithPockets      # noqa: E402
 from src.edm import EDM                                 # noqa: E402
 from src.noise import PredefinedNoiseSchedule           # noqa: E402
 
-from helpers import seeded_state_dict                   # noqa: E402
+from helpers import seeded_state_dict, seeded_size_state_dict   # noqa: E402
 from difflinker_amd import synthetic                    # noqa: E402
 from difflinker_amd.datasets import collate             # noqa: E402
 
@@ -165,6 +165,48 @@ def collate_masks():
     save('collate_masks', atom_mask=atom_mask, edge_mask=edge_mask.view(-1, 1))
 
 
+@torch.no_grad()
+def size_gnn():
+    """Linker-size predictor: the unmodified ``SizeGNN`` (src/linker_size.py:45-91) driven exactly as
+    ``SizeClassifier.forward`` does at inference (src/linker_size_lightning.py:83-110; that module itself needs
+    pytorch_lightning, which this image lacks, so its ten lines of glue are restated here around the reference
+    ``SizeGNN`` and ``coord2diff``)."""
+    from src.linker_size import SizeGNN
+    from src.egnn import coord2diff
+    from difflinker_amd.datasets import collate_with_fragment_edges   # src/datasets.py needs rdkit (absent here)
+    in_nf, hidden, out_nf = 8, 128, 10
+    g = torch.Generator().manual_seed(77)
+    mols = []
+    for n, nl in [(12, 0), (27, 0), (9, 3), (33, 5)]:
+        frag = torch.zeros(n)
+        frag[:n - nl] = 1
+        types = torch.randint(0, in_nf, (n,), generator=g)
+        mols.append({'positions': 1.6 * torch.randn((n, 3), generator=g),
+                     'one_hot': torch.nn.functional.one_hot(types, in_nf).float(),
+                     'anchors': torch.zeros(n), 'fragment_mask': frag, 'linker_mask': 1 - frag,
+                     'num_atoms': n, 'uuid': 0, 'name': 'm'})
+    data = collate_with_fragment_edges(mols)
+    out = {}
+    for tag, n_layers, norm in (('plain', 3, None), ('bn', 2, 'batch_norm')):
+        gnn = SizeGNN(in_node_nf=in_nf, hidden_nf=hidden, out_node_nf=out_nf, n_layers=n_layers, normalization=norm)
+        gnn.load_state_dict(seeded_size_state_dict(in_nf, hidden, out_nf, n_layers, seed=500 + n_layers,
+                                                   batch_norm=norm is not None), strict=True)
+        gnn.eval()
+        h, x = data['one_hot'], data['positions']
+        fragment_mask, edge_mask, edges = data['fragment_mask'], data['edge_mask'], data['edges']
+        x = x * fragment_mask
+        h = h * fragment_mask
+        bs, n_nodes = x.shape[0], x.shape[1]
+        fm = fragment_mask.view(bs * n_nodes, 1)
+        distances, _ = coord2diff(x.view(bs * n_nodes, -1), edges)
+        distance_edge_mask = (edge_mask.bool() & (distances < 6)).long()
+        output = gnn.forward(h.view(bs * n_nodes, -1), edges, distances, fm, distance_edge_mask)
+        out['logits_' + tag] = output.view(bs, n_nodes, -1).mean(1)
+        out['kept_edges_' + tag] = distance_edge_mask.sum()
+    save('size_gnn', one_hot=data['one_hot'], positions=data['positions'], fragment_mask=data['fragment_mask'],
+         linker_mask=data['linker_mask'], edge_mask=data['edge_mask'], **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     gamma_tables()
@@ -172,3 +214,4 @@ if __name__ == '__main__':
     fc_forward()
     fc_chain()
     pocket_forward()
+    size_gnn()

@@ -55,3 +55,53 @@ def rel_l2(a, b):
 
 def max_abs(a, b):
     return float((a.double() - b.double()).abs().max())
+
+
+def size_gnn_param_shapes(in_nf, hidden_nf, out_nf, n_layers, batch_norm=False):
+    """(key, shape, fan_in, kind) of ``SizeGNN`` in ``state_dict`` order (linker_size.py:45-81; egnn.py:19-38)."""
+    out = [('embedding_in.weight', (hidden_nf, in_nf), in_nf, 'w'), ('embedding_in.bias', (hidden_nf,), in_nf, 'b')]
+
+    def gcl(pre):
+        items = [(f'{pre}.edge_mlp.0.weight', (hidden_nf, 2 * hidden_nf + 1), 2 * hidden_nf + 1, 'w'),
+                 (f'{pre}.edge_mlp.0.bias', (hidden_nf,), 2 * hidden_nf + 1, 'b'),
+                 (f'{pre}.edge_mlp.2.weight', (hidden_nf, hidden_nf), hidden_nf, 'w'),
+                 (f'{pre}.edge_mlp.2.bias', (hidden_nf,), hidden_nf, 'b'),
+                 (f'{pre}.node_mlp.0.weight', (hidden_nf, 2 * hidden_nf), 2 * hidden_nf, 'w'),
+                 (f'{pre}.node_mlp.0.bias', (hidden_nf,), 2 * hidden_nf, 'b')]
+        second = 2
+        if batch_norm:
+            items += [(f'{pre}.node_mlp.1.{k}', (hidden_nf,), 0, k) for k in ('weight', 'bias', 'running_mean', 'running_var')]
+            items += [(f'{pre}.node_mlp.1.num_batches_tracked', (), 0, 'count')]
+            second = 3
+        items += [(f'{pre}.node_mlp.{second}.weight', (hidden_nf, hidden_nf), hidden_nf, 'w'),
+                  (f'{pre}.node_mlp.{second}.bias', (hidden_nf,), hidden_nf, 'b')]
+        if batch_norm:
+            items += [(f'{pre}.node_mlp.4.{k}', (hidden_nf,), 0, k) for k in ('weight', 'bias', 'running_mean', 'running_var')]
+            items += [(f'{pre}.node_mlp.4.num_batches_tracked', (), 0, 'count')]
+        return items
+
+    out += gcl('gcl1')
+    for i in range(n_layers - 1):
+        out += gcl(f'gcl_layers.{i}')
+    out += [('embedding_out.weight', (out_nf, hidden_nf), hidden_nf, 'w'), ('embedding_out.bias', (out_nf,), hidden_nf, 'b')]
+    return out
+
+
+def seeded_size_state_dict(in_nf, hidden_nf, out_nf, n_layers, seed, batch_norm=False, prefix=''):
+    """``SizeGNN`` weights from ``numpy.random.default_rng(seed)``; BatchNorm statistics are non-trivial on purpose."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for key, shape, fan_in, kind in size_gnn_param_shapes(in_nf, hidden_nf, out_nf, n_layers, batch_norm):
+        if kind in ('w', 'b'):
+            bound = 1.0 / math.sqrt(fan_in)
+            val = rng.uniform(-bound, bound, size=shape).astype(np.float32)
+        elif kind == 'weight':
+            val = rng.uniform(0.5, 1.5, size=shape).astype(np.float32)
+        elif kind == 'bias' or kind == 'running_mean':
+            val = rng.uniform(-0.3, 0.3, size=shape).astype(np.float32)
+        elif kind == 'running_var':
+            val = rng.uniform(0.5, 2.0, size=shape).astype(np.float32)
+        else:
+            val = np.asarray(7, dtype=np.int64)
+        sd[prefix + key] = torch.from_numpy(np.asarray(val))
+    return sd

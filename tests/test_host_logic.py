@@ -26,11 +26,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dl_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.dl_abi_version() == _lib.ABI_VERSION == 3
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
     cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
     assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == 4 + 6 * 21
+    scfg = _lib.DLSizeConfig(8, 128, 10, 3)
+    assert lib.dl_size_model_num_tensors(ctypes.byref(scfg)) == 4 + 8 * 3
+    assert lib.dl_size_model_num_tensors(ctypes.byref(_lib.DLSizeConfig(8, 64, 10, 3))) == -2
+    assert lib.dl_size_max_fragment_atoms() == 64
 
 
 def test_no_gpu_means_loud_failure_not_fallback():
@@ -194,3 +198,48 @@ def test_shard_bounds_cover_batch():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+@pytest.mark.parametrize('norm', [None, 'batch_norm'])
+def test_size_gnn_state_dict_and_loud_failure(norm):
+    """SizeGNN / SizeClassifier hold the reference's parameters under the reference's keys (linker_size.py:45-81,
+    linker_size_lightning.py:45-52); CPU tensors raise instead of falling back."""
+    from helpers import size_gnn_param_shapes, seeded_size_state_dict
+    from difflinker_amd.linker_size import SizeClassifier, SizeGNN
+    from difflinker_amd import _lib
+    gnn = SizeGNN(in_node_nf=8, hidden_nf=128, out_node_nf=10, n_layers=3, normalization=norm)
+    want = [(k, tuple(shape)) for k, shape, _, _ in size_gnn_param_shapes(8, 128, 10, 3, batch_norm=norm is not None)]
+    got = [(k, tuple(v.shape)) for k, v in gnn.state_dict().items()]
+    assert got == want
+    clf = SizeClassifier(in_node_nf=8, hidden_nf=128, out_node_nf=10, n_layers=3, normalization=norm).eval()
+    clf.load_state_dict(seeded_size_state_dict(8, 128, 10, 3, seed=1, batch_norm=norm is not None, prefix='gnn.'), strict=True)
+    assert clf.linker_id2size[0] == 3 and clf.linker_size2id[12] == 9
+    data = {'one_hot': torch.zeros(1, 4, 8), 'positions': torch.zeros(1, 4, 3), 'fragment_mask': torch.ones(1, 4, 1),
+            'edge_mask': torch.ones(16, 1)}
+    with pytest.raises(_lib.HipLibraryError, match='no CPU fallback'):
+        clf.forward(data, return_loss=False)
+    with pytest.raises(NotImplementedError):
+        clf.forward(data)                      # training objective
+    with pytest.raises(NotImplementedError):
+        SizeGNN(8, 256, 10, 3, None)
+
+
+def test_collate_with_fragment_edges_conventions():
+    """Fragment-only edge mask with the int8 ``~eye`` values (-1 off / -2 on the diagonal) and the FC edge list
+    (datasets.py:378-422)."""
+    from difflinker_amd.datasets import collate_with_fragment_edges
+    mols = []
+    for n, nl in [(3, 1), (2, 0)]:
+        frag = torch.zeros(n)
+        frag[:n - nl] = 1
+        mols.append({'positions': torch.randn(n, 3), 'one_hot': torch.eye(8)[:n], 'anchors': torch.zeros(n),
+                     'fragment_mask': frag, 'linker_mask': 1 - frag, 'num_atoms': n, 'uuid': 0, 'name': 'm'})
+    out = collate_with_fragment_edges(mols)
+    em = out['edge_mask'].view(2, 3, 3)
+    assert em.dtype == torch.float32
+    assert em[0].tolist() == [[-2, -1, 0], [-1, -2, 0], [0, 0, 0]]
+    assert em[1].tolist() == [[-2, -1, 0], [-1, -2, 0], [0, 0, 0]]
+    rows, cols = out['edges']
+    assert rows.tolist()[:9] == [0, 0, 0, 1, 1, 1, 2, 2, 2] and cols.tolist()[:9] == [0, 1, 2] * 3
+    assert rows.tolist()[9:12] == [3, 3, 3] and cols.tolist()[9:12] == [3, 4, 5]
+    assert out['atom_mask'].shape == (2, 3, 1) and out['fragment_mask'].shape == (2, 3, 1)
