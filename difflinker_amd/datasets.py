@@ -48,7 +48,13 @@ def collate(batch):
     return out
 
 
-def collate_with_fragment_edges(batch):
+def collate_with_fragment_without_pocket_edges(batch):
+    """``collate_with_fragment_edges`` for pocket-conditioned inputs (datasets.py:425-469): the edge mask covers the
+    FRAGMENT atoms only ('fragment_only_mask'); pocket atoms stay nodes of the batch but get no size-predictor edges."""
+    return collate_with_fragment_edges(batch, mask_key='fragment_only_mask')
+
+
+def collate_with_fragment_edges(batch, mask_key='fragment_mask'):
     """``collate`` variant used by the generation scripts and the size predictor (datasets.py:378-422): the edge mask
     covers FRAGMENT atoms only and an explicit fully-connected edge list ``[rows, cols]`` (e = b*N*N + i*N + j) is
     attached.  The mask is the float product ``frag_i * frag_j * ~eye`` with ``~eye`` taken on int8, i.e. -1 off the
@@ -66,7 +72,7 @@ def collate_with_fragment_edges(batch):
             continue
         raise Exception(f'Unknown batch key: {key}')
 
-    frag_mask = out['fragment_mask']
+    frag_mask = out[mask_key]
     batch_size, n_nodes = frag_mask.size()
     diag_mask = ~torch.eye(n_nodes, dtype=const.TORCH_INT, device=frag_mask.device).unsqueeze(0)
     edge_mask = frag_mask[:, None, :] * frag_mask[:, :, None] * diag_mask

@@ -1,0 +1,92 @@
+"""CPU tests of the RDKit-free molecule I/O (difflinker_amd/io.py) on hand-made fixtures (tests/golden/io/) and,
+in the build container only, on the reference's case-study files."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from difflinker_amd import const, io
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+IO_DIR = os.path.join(HERE, 'golden', 'io')
+CASES = '/root/reference/case_studies'
+
+
+def test_sdf_first_record_without_hydrogens():
+    m = io.read_molecule(os.path.join(IO_DIR, 'frag.sdf'))
+    assert m.symbols == ['C', 'C', 'N', 'O', 'C', 'Cl', 'S'] and m.name == 'two_fragments'
+    assert np.allclose(m.positions[0], [1.2, 0.0, 0.1]) and np.allclose(m.positions[5], [-5.2, 1.1, 0.6])
+    pos, one_hot, charges = io.parse_molecule(m, is_geom=False)
+    assert pos.shape == (7, 3) and one_hot.shape == (7, 8)
+    assert one_hot.argmax(1).tolist() == [0, 0, 2, 1, 0, 5, 4] and charges.tolist() == [6, 6, 7, 8, 6, 17, 16]
+    assert io.parse_molecule(m, is_geom=True)[1].shape == (7, 9)
+
+
+def test_v3000_mol2_pdb_and_vocabulary_errors():
+    m = io.read_molecule(os.path.join(IO_DIR, 'frag_v3000.mol'))
+    assert m.symbols == ['C', 'Br', 'P'] and np.allclose(m.positions[2], [-4.0, 0.5, 0.0])
+    with pytest.raises(KeyError, match="'P'"):
+        io.parse_molecule(m, is_geom=False)                  # phosphorus only exists in the GEOM vocabulary
+    assert io.parse_molecule(m, is_geom=True)[2].tolist() == [6, 35, 15]
+    m2 = io.read_molecule(os.path.join(IO_DIR, 'lig.mol2'))
+    assert m2.symbols == ['C', 'N', 'Cl'] and m2.name == 'mol2_example'
+    mp = io.read_molecule(os.path.join(IO_DIR, 'lig.pdb'))
+    assert mp.symbols == ['C', 'Cl', 'N']                    # element column, atom-name fallback, altloc A only
+    assert np.allclose(mp.positions[2], [2.5, 0.3, -0.2])
+    with pytest.raises(Exception, match='Unknown file extension'):
+        io.read_molecule(os.path.join(IO_DIR, 'frag.smi'))
+
+
+def test_pocket_extraction_rules():
+    frag = io.read_molecule(os.path.join(IO_DIR, 'frag.sdf'))
+    prot = os.path.join(IO_DIR, 'protein.pdb')
+    pos, one_hot, charges = io.get_pocket(frag, prot)
+    # residue 10 of chain A is in contact; chain B's residue 10 rides along (matched by number only, like the
+    # reference); the zinc ion is in contact but outside the vocabulary; the water oxygen (residue 301) is kept
+    assert pos.shape == (8, 3)
+    assert charges.tolist() == [7, 6, 6, 8, 7, 6, 16, 8]
+    bb = io.get_pocket(frag, prot, backbone_atoms_only=True)
+    assert bb[2].tolist() == [7, 6, 6, 8, 7, 6, 8]           # N CA C O + N CA of chain B + the water 'O'
+    d = io.read_pocket(prot)
+    assert d['full_coord'].shape == (13, 3)                  # 14 records, the two CB alternates are one atom
+    assert d['full_types'].tolist().count('ZN') == 1
+    cb = d['full_coord'][6]
+    assert np.allclose(cb, [32.5, 31.5, 31.5])               # the higher-occupancy location B
+    assert d['bb_types'].tolist() == ['N', 'C', 'C', 'O', 'N', 'C', 'N', 'C', 'O']
+    with pytest.raises(KeyError, match='ZN'):
+        io.pocket_arrays(d, backbone_atoms_only=False)
+    p, oh, ch = io.pocket_arrays(d, backbone_atoms_only=True)
+    assert p.shape == (9, 3) and oh.shape == (9, 9)
+
+
+def test_xyz_roundtrip_and_format(tmp_path):
+    one_hot = torch.eye(9)[[0, 5, 2, 8]].unsqueeze(0)
+    positions = torch.tensor([[[0.1, -2.5, 3.0], [1.0, 2.0, 3.0], [9.0, 9.0, 9.0], [-1.25, 0.0, 4.5]]])
+    node_mask = torch.tensor([[[1], [1], [0], [1]]], dtype=const.TORCH_INT)
+    io.save_xyz_file(str(tmp_path), one_hot, positions, node_mask, names=['mol_7'], is_geom=True, suffix='')
+    path = os.path.join(tmp_path, 'mol_7_.xyz')
+    text = open(path).read()
+    assert text == '3\n\nC 0.100000001 -2.500000000 3.000000000\nCl 1.000000000 2.000000000 3.000000000\n' \
+                   'P -1.250000000 0.000000000 4.500000000\n'
+    pos, oh, ch = io.load_molecule_xyz(path, is_geom=True)
+    assert torch.allclose(pos, positions[0][[0, 1, 3]]) and oh.argmax(1).tolist() == [0, 5, 8] and ch.shape == (3, 1)
+    assert io.load_xyz_files(str(tmp_path)) == [path]
+    back = io.read_molecule(path)
+    assert back.symbols == ['C', 'Cl', 'P']
+
+
+@pytest.mark.skipif(not os.path.isdir(CASES), reason='reference tree only exists in the build container')
+def test_reference_case_study_files_parse():
+    frag = io.read_molecule(os.path.join(CASES, 'hsp90', '3hz1_original_fragments.sdf'))
+    assert len(frag) == 27 and set(frag.symbols) <= set(const.GEOM_ATOM2IDX)
+    pos, one_hot, charges = io.get_pocket(frag, os.path.join(CASES, 'hsp90', '3hz1_protein.pdb'))
+    assert pos.shape[0] == one_hot.shape[0] == charges.shape[0] and 100 < pos.shape[0] < 400
+    # every kept atom belongs to a residue with an atom within 6 A: the closest pocket atom is closer than that
+    d = np.linalg.norm(pos[:, None] - frag.positions[None], axis=-1)
+    assert d.min() <= 6.0
+    bb = io.get_pocket(frag, os.path.join(CASES, 'hsp90', '3hz1_protein.pdb'), backbone_atoms_only=True)
+    assert bb[0].shape[0] < pos.shape[0]
+    for rel in ('impdh/5ou2_fragments_input.sdf', 'jnk/3fi3_fragments.sdf', 'jnk/3fi3_linker.sdf'):
+        m = io.read_molecule(os.path.join(CASES, rel))
+        io.parse_molecule(m, is_geom=True)
