@@ -8,9 +8,56 @@ The int8 quirk is part of the contract: ``edge_mask`` is built in int8 and multi
 ``~eye`` (bitwise NOT on int8: 0 -> -1, 1 -> -2), so real i!=j pairs carry -1, real self
 pairs -2 and any pair with a padded endpoint 0 (datasets.py:366-369, const.py:7).
 """
+import os
+
 import torch
 
 from . import const
+
+
+class ZincDataset(torch.utils.data.Dataset):
+    """List of per-molecule dicts from ``<data_path>/<prefix>.pt`` (datasets.py:40-54).  Building that file from the
+    raw SDF tables is RDKit preprocessing (datasets.py:56-100) and out of scope: a missing file raises."""
+
+    def __init__(self, data_path, prefix, device):
+        dataset_path = os.path.join(data_path, f'{prefix}.pt')
+        if not os.path.exists(dataset_path):
+            raise FileNotFoundError(f'{dataset_path} not found: preprocess the dataset with the reference tooling '
+                                    '(RDKit) first')
+        self.data = torch.load(dataset_path, map_location=device, weights_only=False)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        return self.data[item]
+
+
+class MOADDataset(torch.utils.data.Dataset):
+    """Pocket-conditioned dataset: in-memory ``data`` or ``<data_path>/<prefix>_<pocket_mode>.pt`` for prefixes like
+    ``MOAD_test.full`` / ``MOAD_test_full`` (datasets.py:103-129)."""
+
+    def __init__(self, data=None, data_path=None, prefix=None, device=None):
+        assert (data is not None) or all(x is not None for x in (data_path, prefix, device))
+        if data is not None:
+            self.data = data
+            return
+        if '.' in prefix:
+            prefix, pocket_mode = prefix.split('.')
+        else:
+            parts = prefix.split('_')
+            prefix, pocket_mode = '_'.join(parts[:-1]), parts[-1]
+        dataset_path = os.path.join(data_path, f'{prefix}_{pocket_mode}.pt')
+        if not os.path.exists(dataset_path):
+            raise FileNotFoundError(f'{dataset_path} not found: preprocess the dataset with the reference tooling '
+                                    '(RDKit) first')
+        self.data = torch.load(dataset_path, map_location=device, weights_only=False)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, item):
+        return self.data[item]
 
 
 def collate(batch):
@@ -116,3 +163,8 @@ def create_templates_for_linker_generation(data, linker_sizes):
                 item[k] = t
         decoupled.append(item)
     return collate(decoupled)
+
+
+def get_dataloader(dataset, batch_size, collate_fn=collate, shuffle=False):
+    """datasets.py:472-473."""
+    return torch.utils.data.DataLoader(dataset, batch_size, collate_fn=collate_fn, shuffle=shuffle)

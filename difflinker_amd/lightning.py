@@ -113,7 +113,30 @@ class DDPM(_Base):
         return {'hyper_parameters': dict(self.hparams_dict), 'state_dict': self.state_dict()}
 
     def setup(self, stage=None):
-        raise NotImplementedError('dataset loading needs RDKit-preprocessed files: out of scope (SURVEY section 2)')
+        """Load the preprocessed dataset(s) (lightning.py:115-137); ``stage='val'`` is what the sampling scripts use."""
+        from .datasets import MOADDataset, ZincDataset
+        dataset_type = MOADDataset if '.' in self.train_data_prefix else ZincDataset
+        if stage == 'fit':
+            self.is_geom = ('geom' in self.train_data_prefix) or ('MOAD' in self.train_data_prefix)
+            self.train_dataset = dataset_type(data_path=self.data_path, prefix=self.train_data_prefix, device=self.torch_device)
+            self.val_dataset = dataset_type(data_path=self.data_path, prefix=self.val_data_prefix, device=self.torch_device)
+        elif stage == 'val':
+            self.is_geom = ('geom' in self.val_data_prefix) or ('MOAD' in self.val_data_prefix)
+            self.val_dataset = dataset_type(data_path=self.data_path, prefix=self.val_data_prefix, device=self.torch_device)
+        else:
+            raise NotImplementedError
+
+    def train_dataloader(self, collate_fn=None):
+        from .datasets import collate, get_dataloader
+        return get_dataloader(self.train_dataset, self.batch_size, collate_fn=collate_fn or collate, shuffle=True)
+
+    def val_dataloader(self, collate_fn=None):
+        from .datasets import collate, get_dataloader
+        return get_dataloader(self.val_dataset, self.batch_size, collate_fn=collate_fn or collate)
+
+    def test_dataloader(self, collate_fn=None):
+        from .datasets import collate, get_dataloader
+        return get_dataloader(self.test_dataset, self.batch_size, collate_fn=collate_fn or collate)
 
     def forward(self, data, training):
         raise NotImplementedError('DDPM.forward is the training step (lightning.py:148-199): out of scope')

@@ -4,7 +4,7 @@ runs once before a sampling chain.
 
 The modules hold the parameters under the reference's ``state_dict`` keys; the arithmetic runs in the HIP kernel of
 ``csrc/size_gnn.hip`` through the C ABI (``dl_size_gnn_forward``).  There is no PyTorch fallback: CPU tensors raise.
-Training (``return_loss=True``, BatchNorm in train mode, the ordinal / regression variants) is out of scope.
+Training (gradients, BatchNorm in train mode, the ordinal / regression variants) is out of scope.
 """
 import ctypes
 
@@ -208,10 +208,7 @@ class SizeClassifier(_Base):
         return model
 
     def forward(self, data, return_loss=True, with_pocket=False, adjust_shape=False):
-        """``(logits [B, out_node_nf], loss)`` — linker_size_lightning.py:83-117.  ``return_loss=True`` is the
-        training objective and is out of scope."""
-        if return_loss:
-            raise NotImplementedError('training objective (return_loss=True) is out of scope; pass return_loss=False')
+        """``(logits [B, out_node_nf], loss)`` — linker_size_lightning.py:83-117."""
         h = data['one_hot']
         x = data['positions']
         fragment_mask = data['fragment_only_mask'] if with_pocket else data['fragment_mask']
@@ -224,7 +221,24 @@ class SizeClassifier(_Base):
             rows = data['edges'][0]
             assert rows.numel() == bs * n_nodes * n_nodes, 'the HIP path expects the fully-connected edge list of collate_with_fragment_edges'
         output = self.gnn.predict_logits(h, x, fragment_mask, edge_mask)
-        return output, None
+        loss = None
+        if return_loss:
+            # sample.py:71 calls forward() with the default return_loss=True and discards the loss; it is a [B, classes]
+            # cross-entropy on the HIP logits (no gradient: training is out of scope)
+            weight = None if self.loss_weights is None else torch.as_tensor(self.loss_weights, device=output.device)
+            loss = torch.nn.functional.cross_entropy(output, self.get_true_labels(data['linker_mask']), weight=weight)
+        return output, loss
+
+    def get_true_labels(self, linker_mask):
+        """Class index of every molecule's true linker size; unseen sizes map to the largest class
+        (linker_size_lightning.py:119-129)."""
+        labels = []
+        for size in linker_mask.reshape(linker_mask.shape[0], -1).sum(-1).long().detach().cpu().numpy():
+            label = self.linker_size2id.get(int(size))
+            if label is None:
+                label = self.linker_size2id[max(self.linker_id2size)]
+            labels.append(label)
+        return torch.tensor(labels, device=linker_mask.device, dtype=torch.long)
 
     def sample_sizes(self, data, with_pocket=False):
         """The ``sample_fn`` closure of generate.py:86-99 as a method: softmax -> Categorical -> size table."""

@@ -101,3 +101,75 @@ def test_generate_with_protein_hides_pocket_and_is_seed_reproducible(tmp_path):
     f3 = generate_with_pocket(os.path.join(IO_DIR, 'frag.sdf'), prot, output_dir=str(tmp_path / 'p4'),
                               **dict(kw, backbone_atoms_only=True))
     assert len(read_xyz(f3[0])[0]) == len(frag) + 3
+
+
+def toy_dataset(n_mols, nf, pockets, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    data = []
+    for k in range(n_mols):
+        n_frag, n_link, n_pock = 6 + k, 3, (7 if pockets else 0)
+        n = n_frag + n_pock + n_link
+        frag_only = torch.zeros(n); frag_only[:n_frag] = 1
+        pock = torch.zeros(n); pock[n_frag:n_frag + n_pock] = 1
+        link = torch.zeros(n); link[n_frag + n_pock:] = 1
+        item = {'uuid': k, 'name': f'mol{k}', 'positions': 2.0 * torch.randn((n, 3), generator=g),
+                'one_hot': torch.nn.functional.one_hot(torch.randint(0, nf, (n,), generator=g), nf).float(),
+                'charges': torch.zeros(n), 'anchors': torch.zeros(n), 'fragment_mask': frag_only + pock,
+                'linker_mask': link, 'num_atoms': n}
+        if pockets:
+            item['fragment_only_mask'] = frag_only
+            item['pocket_mask'] = pock
+        data.append({k_: (v.to(device) if torch.is_tensor(v) else v) for k_, v in item.items()})
+    return data
+
+
+@pytest.mark.parametrize('pockets', [False, True])
+def test_sample_driver_writes_and_resumes(tmp_path, pockets):
+    """sample.py's loop on a preprocessed toy set: ground truth / fragments (/ pocket) once, n_samples molecules per
+    entry, a second call regenerates nothing."""
+    from difflinker_amd import DDPM
+    from difflinker_amd.sample import sample
+    dev = 'cuda:0'
+    prefix = 'MOAD_test.full' if pockets else 'zinc_final_test'
+    torch.save(toy_dataset(3, 9 if pockets else 8, pockets, seed=3, device=dev),
+               os.path.join(tmp_path, 'MOAD_test_full.pt' if pockets else 'zinc_final_test.pt'))
+    torch.manual_seed(0)
+    hp = ddpm_hparams(pockets)
+    hp.update(batch_size=2, data_path=str(tmp_path))
+    ddpm = DDPM(**hp)
+    torch.manual_seed(5)
+    out = sample(ddpm, str(tmp_path / 'samples'), prefix, n_samples=2, device=dev, n_steps=4)
+    for u, n_frag in zip('012', (6, 7, 8)):
+        files = sorted(os.listdir(os.path.join(out, u)))
+        assert files == (['0_.xyz', '1_.xyz', 'frag_.xyz'] + (['pock_.xyz'] if pockets else []) + ['true_.xyz'])
+        assert len(read_xyz(os.path.join(out, u, 'frag_.xyz'))[0]) == n_frag
+        assert len(read_xyz(os.path.join(out, u, 'true_.xyz'))[0]) == n_frag + 3
+        if pockets:
+            assert len(read_xyz(os.path.join(out, u, 'pock_.xyz'))[0]) == 7
+        syms, pos = read_xyz(os.path.join(out, u, '1_.xyz'))
+        assert len(syms) == n_frag + 3 and np.isfinite(pos).all()
+        # fragments are written in the same (centre-of-mass) frame as the ground truth
+        fsyms, fpos = read_xyz(os.path.join(out, u, 'frag_.xyz'))
+        assert syms[:n_frag] == fsyms and np.abs(pos[:n_frag] - fpos).max() <= 1e-4
+    stamp = {u: os.path.getmtime(os.path.join(out, u, '1_.xyz')) for u in '012'}
+    sample(ddpm, str(tmp_path / 'samples'), prefix, n_samples=2, device=dev, n_steps=4)
+    assert stamp == {u: os.path.getmtime(os.path.join(out, u, '1_.xyz')) for u in '012'}
+
+
+def test_sample_trajectories_driver(tmp_path):
+    from difflinker_amd import DDPM
+    from difflinker_amd.sample import sample_trajectories
+    dev = 'cuda:0'
+    torch.save(toy_dataset(2, 8, False, seed=4, device=dev), os.path.join(tmp_path, 'zinc_final_test.pt'))
+    torch.manual_seed(0)
+    hp = ddpm_hparams(False)
+    hp.update(data_path=str(tmp_path))
+    ddpm = DDPM(**hp)
+    chains_dir, final_dir = sample_trajectories(ddpm, str(tmp_path / 'chains'), 'zinc_final_test', keep_frames=3,
+                                                device=dev, n_steps=6)
+    assert sorted(os.listdir(chains_dir)) == ['0', '1']
+    assert sorted(os.listdir(os.path.join(chains_dir, '1'))) == ['1_0_.xyz', '1_1_.xyz', '1_2_.xyz']
+    assert sorted(os.listdir(final_dir)) == ['0_pred_.xyz', '0_true_.xyz', '1_pred_.xyz', '1_true_.xyz']
+    assert len(read_xyz(os.path.join(final_dir, '1_pred_.xyz'))[0]) == 7 + 3
+    # frame 0 of the chain is the final sample
+    assert open(os.path.join(chains_dir, '1', '1_0_.xyz')).read() == open(os.path.join(final_dir, '1_pred_.xyz')).read()

@@ -219,8 +219,6 @@ def test_size_gnn_state_dict_and_loud_failure(norm):
     with pytest.raises(_lib.HipLibraryError, match='no CPU fallback'):
         clf.forward(data, return_loss=False)
     with pytest.raises(NotImplementedError):
-        clf.forward(data)                      # training objective
-    with pytest.raises(NotImplementedError):
         SizeGNN(8, 256, 10, 3, None)
 
 
@@ -243,3 +241,64 @@ def test_collate_with_fragment_edges_conventions():
     assert rows.tolist()[:9] == [0, 0, 0, 1, 1, 1, 2, 2, 2] and cols.tolist()[:9] == [0, 1, 2] * 3
     assert rows.tolist()[9:12] == [3, 3, 3] and cols.tolist()[9:12] == [3, 4, 5]
     assert out['atom_mask'].shape == (2, 3, 1) and out['fragment_mask'].shape == (2, 3, 1)
+
+
+def _toy_dataset(n_mols, nf, pockets=False, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    data = []
+    for k in range(n_mols):
+        n_frag, n_link, n_pock = 6 + k, 3, (5 if pockets else 0)
+        n = n_frag + n_pock + n_link
+        frag_only = torch.zeros(n); frag_only[:n_frag] = 1
+        pock = torch.zeros(n); pock[n_frag:n_frag + n_pock] = 1
+        link = torch.zeros(n); link[n_frag + n_pock:] = 1
+        item = {'uuid': k, 'name': f'mol{k}', 'positions': 2.0 * torch.randn((n, 3), generator=g),
+                'one_hot': torch.nn.functional.one_hot(torch.randint(0, nf, (n,), generator=g), nf).float(),
+                'charges': torch.zeros(n), 'anchors': torch.zeros(n), 'fragment_mask': frag_only + pock,
+                'linker_mask': link, 'num_atoms': n}
+        if pockets:
+            item['fragment_only_mask'] = frag_only
+            item['pocket_mask'] = pock
+        data.append(item)
+    return data
+
+
+def test_datasets_setup_and_resume_logic(tmp_path):
+    """Preprocessed-dataset loaders (datasets.py:40-54, :103-129), DDPM.setup('val') / val_dataloader
+    (lightning.py:115-146) and sample.py's resume rule (sample.py:37-60)."""
+    from difflinker_amd import DDPM
+    from difflinker_amd.datasets import MOADDataset, ZincDataset, collate_with_fragment_edges
+    from difflinker_amd.sample import check_if_generated
+    torch.save(_toy_dataset(5, 8), os.path.join(tmp_path, 'zinc_final_test.pt'))
+    torch.save(_toy_dataset(3, 9, pockets=True), os.path.join(tmp_path, 'MOAD_test_full.pt'))
+    assert len(ZincDataset(str(tmp_path), 'zinc_final_test', 'cpu')) == 5
+    assert len(MOADDataset(data_path=str(tmp_path), prefix='MOAD_test.full', device='cpu')) == 3
+    assert len(MOADDataset(data_path=str(tmp_path), prefix='MOAD_test_full', device='cpu')) == 3
+    with pytest.raises(FileNotFoundError, match='preprocess'):
+        ZincDataset(str(tmp_path), 'zinc_final_train', 'cpu')
+    hp = dict(in_node_nf=8, n_dims=3, context_node_nf=1, hidden_nf=128, activation='silu', tanh=False, n_layers=1,
+              attention=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+              aggregation_method='sum', diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+              diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4, 10],
+              include_charges=False, model='egnn_dynamics', data_path=str(tmp_path), train_data_prefix='zinc_final_train',
+              val_data_prefix='zinc_final_test', batch_size=2, lr=2e-4, torch_device='cpu', test_epochs=20,
+              n_stability_samples=10, normalization='batch_norm', anchors_context=False)
+    m = DDPM(**hp)
+    m.setup(stage='val')
+    batches = list(m.val_dataloader(collate_fn=collate_with_fragment_edges))
+    assert [len(b['uuid']) for b in batches] == [2, 2, 1] and 'edges' in batches[0]
+    assert batches[0]['positions'].shape == (2, 10, 3) and batches[0]['edge_mask'].shape == (200, 1)
+    with pytest.raises(NotImplementedError):
+        m.setup(stage='test')
+    # resume rule: nothing there -> start at 0; files 0..k -> restart two back; complete -> generated
+    out = os.path.join(tmp_path, 'out')
+    for u in ('0', '1'):
+        os.makedirs(os.path.join(out, u))
+    assert check_if_generated(out, ['0', '1'], 3) == (False, 0)
+    for i in range(3):
+        open(os.path.join(out, '0', f'{i}_.xyz'), 'w').close()
+    for i in range(2):
+        open(os.path.join(out, '1', f'{i}_.xyz'), 'w').close()
+    open(os.path.join(out, '1', 'true_.xyz'), 'w').close()
+    assert check_if_generated(out, ['0', '1'], 3) == (False, 0)
+    assert check_if_generated(out, ['0'], 3) == (True, None)
