@@ -43,6 +43,8 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
     ap.add_argument('--T', type=int, default=None, help='reverse steps (default: the config\'s, 500 for C2)')
     ap.add_argument('--uniform-size', action='store_true', help='unpadded variant: every molecule has N atoms')
+    ap.add_argument('--noise', default='torch', choices=['torch', 'philox'],
+                    help="'torch': the reference's torch.randn stream (default); 'philox': draws generated inside the kernel")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-forwards', type=int, default=2)
     return ap.parse_args()
@@ -147,6 +149,7 @@ def main():
     inp = {k: v.to(device) for k, v in inp_cpu.items()}    # inputs resident in HBM before the timed region
     B, N = inp['x'].shape[:2]
     edm = build_model(cfg, device)
+    edm.noise_source = a.noise
     edm.profile_events = True
     pairs, nodes = synthetic.pair_and_node_counts(data)
     if pockets:
@@ -194,15 +197,15 @@ def main():
             # the 128-wide contractions run as 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
             # ALGORITHMIC-flop ceiling of the scheme is the dense f16 MFMA peak / 3
             peak, peak_note = F16_MFMA_PEAK_TFLOPS / 3.0, \
-                'dense f16 MFMA peak 2500 TFLOP/s / 3 split terms (fp32-equivalent result); the kernel is bound by ' \
-                'v_exp_f32/v_rcp_f32 throughput (2 SiLU per pair and channel), not by the matrix pipe'
+                'dense f16 MFMA peak 2500 TFLOP/s / 3 split terms (fp32-equivalent result); the pair loop is issue-bound on ' \
+                'VALU (2 SiLU per pair and channel + fp16 splits) + matrix time, see DESIGN.md'
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
         out = {
             'metric': 'molecules/sec (500-step sample_chain)', 'value': B * world * a.steps / elapsed,
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic', 'noise': a.noise,
             'config': {'workload': f'{a.config}: {"GEOM geom_difflinker" if not pockets else "pockets_difflinker_full_no_anchors_fc (FC-10A-4A radius graph)"} hparams (egnn_dynamics, hidden 128, '
                                    f'{cfg["n_layers"]} blocks), batch={B} molecules/GPU padded to N={N} '
                                    f'(n_b {"= N" if a.uniform_size else ("~ U{35..50}" if not pockets else "30 fragment + 250 pocket + 6..12 linker atoms")}), T={cfg["T"]} reverse steps '

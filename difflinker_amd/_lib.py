@@ -44,6 +44,7 @@ class DLChainArgs(ctypes.Structure):
         ('x', ctypes.c_void_p), ('h', ctypes.c_void_p), ('node_mask', ctypes.c_void_p),
         ('fragment_mask', ctypes.c_void_p), ('linker_mask', ctypes.c_void_p), ('edge_mask', ctypes.c_void_p),
         ('context', ctypes.c_void_p), ('noise_x', ctypes.c_void_p), ('noise_h', ctypes.c_void_p),
+        ('noise_seed', ctypes.c_uint64), ('mol_offset', ctypes.c_int32), ('reserved', ctypes.c_int32),
         ('coefs', ctypes.c_void_p),
         ('inv_alpha0', ctypes.c_float), ('sigma0', ctypes.c_float), ('sigma_x', ctypes.c_float),
         ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float),
@@ -55,7 +56,7 @@ EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_stri
            'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
            'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
            'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
-           'dl_size_gnn_forward')
+           'dl_size_gnn_forward', 'dl_philox_fill')
 
 _lib = None
 
@@ -102,6 +103,8 @@ def load():
     lib.dl_egnn_forward_pocket.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dl_sample_chain_fc.restype = i32
     lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
+    lib.dl_philox_fill.restype = i32
+    lib.dl_philox_fill.argtypes = [ctypes.c_uint64, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dl_size_model_num_tensors.restype = i32
     lib.dl_size_model_num_tensors.argtypes = [ctypes.POINTER(DLSizeConfig)]
     lib.dl_size_model_create.restype = i32

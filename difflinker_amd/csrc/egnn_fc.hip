@@ -28,6 +28,8 @@
 #include <math.h>
 #include <cmath>
 
+#include <algorithm>
+
 #include "../../include/difflinker_hip.h"
 #include "pack_layout.h"
 
@@ -922,13 +924,15 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         for (int k = 0; k < p.md.ctx; ++k) v.ctx[tid * CTXMAX + k] = g.context[n * p.md.ctx + k];
     }
     __syncthreads();
+    const bool philox = (g.noise_x == nullptr);                // draws generated in place (pack_layout.h: philox_normal)
     // z = normalize(x,h) * fragment_mask + noise_0 * linker_mask   (edm.py:132-137,347-350)
     for (int e = tid; e < nb * D; e += THREADS) {
         const int a = e / D, d = e - a * D;
         const size_t n = size_t(b) * N + v.idx[a];
         float val, eps0;
-        if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = g.noise_x[n * 3 + d]; }
-        else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = g.noise_h[n * nf + d - 3]; }
+        if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = philox ? 0.0f : g.noise_x[n * 3 + d]; }
+        else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = philox ? 0.0f : g.noise_h[n * nf + d - 3]; }
+        if (philox) eps0 = philox_normal(g.noise_seed, unsigned(g.mol_offset + b), unsigned(v.idx[a]), 0u, unsigned(d));
         const float lm = v.lm[a];
         v.z[a * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[a]), __fmul_rn(__fmul_rn(eps0, lm), lm));
     }
@@ -959,8 +963,9 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
             const float lm = v.lm[a];
             const float zt = v.z[a * DMAX + d];
             const float eh = __fmul_rn(v.A[a * DMAX + d], lm);
-            const float nz = (d < 3) ? g.noise_x[(q + 1) * nx_stride + n * 3 + d]
-                                     : g.noise_h[(q + 1) * nh_stride + n * nf + d - 3];
+            float nz;
+            if (philox) nz = philox_normal(g.noise_seed, unsigned(g.mol_offset + b), unsigned(v.idx[a]), unsigned(q + 1), unsigned(d));
+            else nz = (d < 3) ? g.noise_x[(q + 1) * nx_stride + n * 3 + d] : g.noise_h[(q + 1) * nh_stride + n * nf + d - 3];
             float zn;
             if (!decode) {
                 // z_s = z_t*frag + (z_t/alpha - c_eps*(eps*lm) + sigma*(noise*lm))*lm   (edm.py:196-206)
@@ -1275,8 +1280,9 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float*
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stream) {
     if (!m || !g) return DL_ERR_BAD_ARG;
-    if (!g->x || !g->h || !g->node_mask || !g->fragment_mask || !g->linker_mask || !g->noise_x || !g->noise_h ||
+    if (!g->x || !g->h || !g->node_mask || !g->fragment_mask || !g->linker_mask ||
         !g->coefs || !g->chain || !g->nan_flags || !g->nan_step) return DL_ERR_BAD_ARG;
+    if ((g->noise_x == nullptr) != (g->noise_h == nullptr)) return DL_ERR_BAD_ARG;    // both (bank) or neither (Philox)
     if (m->cfg.context_node_nf > 0 && !g->context) return DL_ERR_BAD_ARG;
     if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T) return DL_ERR_BAD_ARG;
     if (g->B == 0) return DL_OK;
@@ -1288,6 +1294,35 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     else
         hipLaunchKernelGGL(sample_chain_fc_kernel<0>, dim3(g->B), dim3(THREADS), 0,
                            static_cast<hipStream_t>(stream), a);
+    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+
+namespace {
+__global__ void philox_fill_kernel(unsigned long long seed, int mol_offset, int B, int N, int nf, int draw0, int n_draws,
+                                   float* noise_x, float* noise_h) {
+    const int D = 3 + nf;
+    const long long total = (long long)n_draws * B * N * D;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int d = int(e % D);
+        const long long node = e / D;                      // (k * B + b) * N + n
+        const int n = int(node % N);
+        const int b = int((node / N) % B);
+        const int k = int(node / ((long long)N * B));
+        const float val = philox_normal(seed, unsigned(mol_offset + b), unsigned(n), unsigned(draw0 + k), unsigned(d));
+        if (d < 3) noise_x[node * 3 + d] = val;
+        else noise_h[node * nf + d - 3] = val;
+    }
+}
+}  // namespace
+
+int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, int32_t B, int32_t N, int32_t nf, int32_t draw0,
+                       int32_t n_draws, float* noise_x, float* noise_h, void* stream) {
+    if (!noise_x || !noise_h || B < 0 || N < 1 || nf < 1 || n_draws < 0 || draw0 < 0 || mol_offset < 0) return DL_ERR_BAD_ARG;
+    const long long total = (long long)n_draws * B * N * (3 + nf);
+    if (total == 0) return DL_OK;
+    const int blocks = int(std::min<long long>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(philox_fill_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       (unsigned long long)seed, mol_offset, B, N, nf, draw0, n_draws, noise_x, noise_h);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
 

@@ -151,4 +151,31 @@ __device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, i
     return b;
 }
 
+// ---- counter-based noise: Philox4x32-10 keyed by the caller's seed; the counter is
+// (global molecule index, atom position inside the molecule, draw index, component / 4), so a sample does not depend on
+// the batch split across GPUs, on the batch size or on the padded width.  Four 32-bit outputs -> four standard normals
+// by Box-Muller on (u + 0.5) * 2^-32.  Restated for the CPU in oracle/philox_oracle.py.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = unsigned(p1 >> 32) ^ c1 ^ k0, n1 = unsigned(p1), n2 = unsigned(p0 >> 32) ^ c3 ^ k1, n3 = unsigned(p0);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// standard normal number `comp` of draw `draw` for atom `atom` of global molecule `mol`
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned mol, unsigned atom, unsigned draw, unsigned comp) {
+    unsigned r[4];
+    philox4x32_10(mol, atom, draw, comp >> 2, unsigned(seed), unsigned(seed >> 32), r);
+    const unsigned pair = comp & 2u;                                   // components 0,1 use r[0],r[1]; 2,3 use r[2],r[3]
+    const float u1 = (float(r[pair] >> 8) + 0.5f) * 5.9604644775390625e-08f;       // 24 bits -> (0,1)
+    const float u2 = (float(r[pair + 1] >> 8) + 0.5f) * 5.9604644775390625e-08f;
+    const float rad = sqrtf(-2.0f * logf(u1));
+    return rad * ((comp & 1u) ? sinpif(2.0f * u2) : cospif(2.0f * u2));
+}
+
 }  // namespace

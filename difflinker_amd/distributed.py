@@ -69,9 +69,11 @@ def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=N
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     bs, n = inputs['x'].shape[0], inputs['x'].shape[1]
     local, (lo, hi) = shard_sampler_inputs(inputs, rank, world)
-    if noise_bank is None and world > 1:
-        noise_bank = edm.draw_noise_bank(bs, n, inputs['x'].device)
     kw = {}
+    if noise_bank is None and getattr(edm, 'noise_source', 'torch') == 'philox':
+        kw['mol_offset'] = lo                 # counter-based draws: nothing to generate or slice, any world size
+    elif noise_bank is None and world > 1:
+        noise_bank = edm.draw_noise_bank(bs, n, inputs['x'].device)
     if noise_bank is not None:
         kw['noise_bank'] = (noise_bank[0][:, lo:hi].contiguous(), noise_bank[1][:, lo:hi].contiguous())
     chain = edm.sample_chain(keep_frames=keep_frames, **local, **kw)

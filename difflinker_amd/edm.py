@@ -46,6 +46,12 @@ class EDM(torch.nn.Module):
         self.T = timesteps                      # callers overwrite it for --n_steps (generate.py:103-104)
         self.norm_values = norm_values
         self.norm_biases = norm_biases
+        # 'torch' (default): the reference's own stream — torch.randn on the device in the reference's call order, so the
+        # same torch.manual_seed reproduces the reference's draws.  'philox': counter-based draws generated inside the
+        # kernels (no 2(T+2) randn launches, no noise bank in HBM), keyed by (noise_seed, global molecule index, atom,
+        # draw) and therefore independent of the batch split; noise_seed advances by one per sampled chain.
+        self.noise_source = 'torch'
+        self.noise_seed = 0
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError('EDM.forward is the training loss (edm.py:41-124): out of scope of the '
@@ -209,19 +215,22 @@ class EDM(torch.nn.Module):
 
     @torch.no_grad()
     def sample_chain(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames=None,
-                     noise_bank=None):
+                     noise_bank=None, mol_offset=0):
         """``EDM.sample_chain`` (edm.py:126-176).  Returns ``chain [keep_frames, B, N, 3+nf]`` whose frame 0
         is the final sample ``[x, one_hot(h)]``.
 
         ``noise_bank`` (optional, not in the reference signature) = ``(noise_x [T+2,B,N,3], noise_h
         [T+2,B,N,nf])`` replaces the internal ``torch.randn`` draws (parity tests share one bank with the
-        CPU oracle).
+        CPU oracle).  ``mol_offset``: global index of the first molecule of this batch (``noise_source='philox'``
+        with a batch sharded over ranks).
         """
         if keep_frames is None:
             keep_frames = self.T
         else:
             assert keep_frames <= self.T
         if not self._fused_ok():
+            if noise_bank is None and self.noise_source == 'philox':
+                noise_bank = self.philox_noise_bank(x.size(0), x.size(1), x.device, mol_offset)
             return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
                                                 keep_frames, noise_bank)
         dev = x.device
@@ -231,7 +240,13 @@ class EDM(torch.nn.Module):
         bs, n = x.size(0), x.size(1)
         nf, T = self.in_node_nf, self.T
         handle = self.dynamics.hip_model(dev)
-        if noise_bank is None:
+        philox = noise_bank is None and self.noise_source == 'philox'
+        seed = 0
+        if philox:
+            noise_x = noise_h = None
+            seed = int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF
+            self.noise_seed = int(self.noise_seed) + 1
+        elif noise_bank is None:
             noise_x, noise_h = self.draw_noise_bank(bs, n, dev)
         else:
             noise_x, noise_h = (t.to(dev, torch.float32).contiguous() for t in noise_bank)
@@ -252,7 +267,8 @@ class EDM(torch.nn.Module):
             x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
             linker_mask=lm.data_ptr(), edge_mask=em.data_ptr() if em is not None else None,
             context=ctx.data_ptr() if ctx is not None else None,
-            noise_x=noise_x.data_ptr(), noise_h=noise_h.data_ptr(), coefs=coefs.data_ptr(),
+            noise_x=None if philox else noise_x.data_ptr(), noise_h=None if philox else noise_h.data_ptr(),
+            noise_seed=seed, mol_offset=int(mol_offset), reserved=0, coefs=coefs.data_ptr(),
             inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
             norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
             chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr())
@@ -268,6 +284,23 @@ class EDM(torch.nn.Module):
                 self.last_kernel_events = (ev0, ev1)
         self._raise_on_chain_flags(flags, steps)
         return chain
+
+    def philox_noise_bank(self, n_samples, n_nodes, device, mol_offset=0, seed=None):
+        """The in-kernel stream as a bank ``(noise_x [T+2,B,N,3], noise_h [T+2,B,N,nf])`` (``dl_philox_fill``); advances
+        ``noise_seed`` unless ``seed`` is given."""
+        if torch.device(device).type != 'cuda':
+            raise RuntimeError('the Philox noise bank is generated on the GPU (no CPU fallback)')
+        if seed is None:
+            seed = int(self.noise_seed)
+            self.noise_seed = seed + 1
+        noise_x = torch.empty((self.T + 2, n_samples, n_nodes, self.n_dims), device=device)
+        noise_h = torch.empty((self.T + 2, n_samples, n_nodes, self.in_node_nf), device=device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(_lib.load().dl_philox_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset), n_samples, n_nodes,
+                                                  self.in_node_nf, 0, self.T + 2, noise_x.data_ptr(), noise_h.data_ptr(),
+                                                  ctypes.c_void_p(stream)), 'dl_philox_fill')
+        return noise_x, noise_h
 
     def _raise_on_chain_flags(self, flags, steps):
         """The reference raises at the first denoiser call whose output holds a NaN (egnn.py:441-442);

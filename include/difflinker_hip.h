@@ -161,6 +161,10 @@ typedef struct dl_chain_args {
     const float* context;       /* device [B,N,ctx]                                            */
     const float* noise_x;       /* device [T+2,B,N,3]  standard normal draws, reference order: */
     const float* noise_h;       /* device [T+2,B,N,nf] draw 0 = initial z, 1..T = steps, T+1 = decode */
+                                /* both NULL: the draws are generated inside the kernel (dl_philox_fill's stream) */
+    uint64_t noise_seed;        /* key of the in-kernel generator                                          */
+    int32_t mol_offset;         /* global index of molecule 0 of this batch (shards of one logical batch)  */
+    int32_t reserved;
     const dl_step_coef* coefs;  /* device [T]       execution order (s = T-1 first)            */
     float inv_alpha0, sigma0, sigma_x;      /* final decode scalars (src/edm.py:213-216,237-242) */
     float norm_x, norm_h, bias_h;           /* norm_values[0], norm_values[1], norm_biases[1]    */
@@ -170,6 +174,12 @@ typedef struct dl_chain_args {
 } dl_chain_args;
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
+
+/* The in-kernel noise stream as a bank (for host-driven loops and tests): Philox4x32-10, key = seed, counter =
+ * (mol_offset + b, atom position n, draw0 + k, component / 4), four outputs -> four standard normals by Box-Muller;
+ * component d < 3 is noise_x[k][b][n][d], d >= 3 is noise_h[k][b][n][d-3].  Independent of the batch split. */
+int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, int32_t B, int32_t N, int32_t nf, int32_t draw0,
+                       int32_t n_draws, float* noise_x, float* noise_h, void* stream);
 
 /* Diagnostics: when set (device uint64 [8 waves][dl_profile_max_events()][2], or NULL to disable), the
  * first workgroup of the next launches logs (phase tag, shader clock) pairs of its first forward. */
