@@ -201,6 +201,17 @@ def main():
                 'VALU (2 SiLU per pair and channel + fp16 splits) + matrix time, see DESIGN.md'
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
+        # fabric-side bytes per launch from the committed rocprofv3 --pmc passes of this kernel (profiles/, collected at
+        # T=20 = 21 forwards by scripts/profile_gpu.sh; FETCH_SIZE already doubled for gfx950), scaled to this launch
+        traffic, traffic_note = None, None
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_final', 'pmc_chain_kernel_T20.json')
+        if not pockets and precision == 'f16x3' and a.config == 'C2' and not a.uniform_size and os.path.exists(pmc_path):
+            d_ = json.load(open(pmc_path))['_derived']
+            per_fwd = (d_['hbm_fetch_bytes_per_launch_x2_corrected'] + d_['hbm_write_bytes_per_launch']) / 21.0
+            traffic = per_fwd * (cfg['T'] + 1) * (B / 256.0)
+            traffic_note = 'FETCH_SIZE x2 + WRITE_SIZE of profiles/r01_final/pmc_chain_kernel_T20.json (T=20 launch) scaled by ' \
+                           'forwards; fabric-side, Infinity-Cache hits included (spill scratch + weight streaming); ' \
+                           'algorithmic HBM bytes are ~2 MB per forward'
         out = {
             'metric': 'molecules/sec (500-step sample_chain)', 'value': B * world * a.steps / elapsed,
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -214,7 +225,7 @@ def main():
                        'global_batch': B * world, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}',
                        'real_pairs_per_forward': pairs, 'real_atoms': nodes},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None, 'peak_note': peak_note,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
                          'frac_of_fp32_vector_peak': achieved / FP32_MFMA_PEAK_TFLOPS,
                          'kernel': 'sample_chain_fc_kernel' if not pockets else 'all kernels of the chain (pk_edge_kernel dominates)', 'kernel_ms': k_avg_ms,
                          'flops_per_launch': flops_fwd * (cfg['T'] + 1)},
