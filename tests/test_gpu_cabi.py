@@ -1,0 +1,65 @@
+"""The C ABI on its own (include/difflinker_hip.h through raw ctypes; PyTorch only provides the device buffers): a host
+that is not the Python drop-in gets the same numbers and the documented status codes."""
+import ctypes
+
+import pytest
+import torch
+
+from helpers import seeded_state_dict, rel_l2
+from oracle import egnn_oracle
+from oracle.egnn_oracle import EGNNConfig
+from test_gpu_parity import ragged_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
+    from difflinker_amd import _lib
+    from difflinker_amd.egnn import egnn_tensor_order
+    lib = _lib.load()
+    nf, ctx, L = 9, 1, 2
+    sd = seeded_state_dict(nf + ctx + 1, 128, L, seed=123)
+    host = [sd['dynamics.' + k].contiguous() for k in egnn_tensor_order(L)]
+    cfg = _lib.DLConfig(3, nf, ctx, 128, L, 2, 1, 1e-6, 100.0, 1)
+    assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == len(host)
+    ptrs = (ctypes.c_void_p * len(host))(*[t.data_ptr() for t in host])
+    model = ctypes.c_void_p()
+    assert lib.dl_model_create(ctypes.byref(cfg), ptrs, len(host), ctypes.byref(model)) == 0
+    try:
+        inp, z, t = ragged_inputs([20, 55, 9], [4, 7, 2], nf, seed=5)
+        B, N = z.shape[:2]
+        d = torch.device('cuda:0')
+        xh, tt = z.to(d).contiguous(), t.to(d).contiguous()
+        nm = inp['node_mask'].reshape(B, N).to(torch.int8).to(d).contiguous()
+        lm = inp['linker_mask'].reshape(B, N).float().to(d).contiguous()
+        em = inp['edge_mask'].reshape(B, N, N).to(torch.int8).to(d).contiguous()
+        cx = inp['context'].reshape(B, N, ctx).float().to(d).contiguous()
+        out = torch.full((B, N, 3 + nf), float('nan'), device=d)
+        flags = torch.full((B,), -1, dtype=torch.int32, device=d)
+        p = lambda x: ctypes.c_void_p(x.data_ptr())          # noqa: E731
+        st = lib.dl_egnn_forward_fc(model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None)
+        assert st == 0
+        torch.cuda.synchronize()
+        ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
+                                           t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        assert rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= 2e-5 and flags.cpu().tolist() == [0, 0, 0]
+        # status codes: null pointer, negative batch, a molecule with more atoms than dl_max_atoms() (flag bit 2)
+        assert lib.dl_egnn_forward_fc(model, B, N, None, p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == -1
+        assert lib.dl_egnn_forward_fc(model, -1, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == -1
+        assert lib.dl_egnn_forward_fc(model, 0, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == 0
+        big, zb, tb = ragged_inputs([56], [3], nf, seed=6)
+        xb = zb.to(d).contiguous()
+        nmb = big['node_mask'].reshape(1, 56).to(torch.int8).to(d).contiguous()
+        lmb = big['linker_mask'].reshape(1, 56).float().to(d).contiguous()
+        emb = big['edge_mask'].reshape(1, 56, 56).to(torch.int8).to(d).contiguous()
+        cxb = big['context'].reshape(1, 56, ctx).float().to(d).contiguous()
+        outb = torch.empty((1, 56, 3 + nf), device=d)
+        fb = torch.zeros((1,), dtype=torch.int32, device=d)
+        assert lib.dl_egnn_forward_fc(model, 1, 56, p(xb), p(tb.to(d)), 0, p(nmb), p(lmb), p(emb), p(cxb), p(outb), p(fb), None) == 0
+        torch.cuda.synchronize()
+        assert int(fb.cpu()[0]) & 4 and float(outb.abs().max()) == 0.0
+    finally:
+        lib.dl_model_destroy(model)
+    bad = _lib.DLConfig(3, nf, ctx, 64, L, 2, 1, 1e-6, 100.0, 1)              # hidden_nf != 128
+    assert lib.dl_model_create(ctypes.byref(bad), ptrs, len(host), ctypes.byref(model)) == -2
+    assert lib.dl_error_string(-3).decode().startswith('molecule exceeds')
