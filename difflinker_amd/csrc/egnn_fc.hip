@@ -51,12 +51,13 @@ __device__ __forceinline__ bool grid_wave(int w) { return NWAVES == GWAVES || w 
 static_assert(THREADS == 512 || THREADS == 768, "8 grid waves + 0 or 4 helper waves");
 // pair-tile shares of the waves sharing a SIMD (w, w+4[, w+8]), oldest first: the older wave wins the issue
 // arbitration and gets through more tiles per unit time; static, contiguous ranges (deterministic reduction).
-// Measured (n = 50, ticks per forward): 8:8 4.13 M, 9:7 4.01 M, 10:6 3.94 M, 12:4 4.11 M, one wave only 4.97 M.
+// Measured (n = 50, ticks per forward; before / after the spill clean-up): 8:8 4.13 M, 9:7 4.01 M, 10:6 3.94 / 3.38 M,
+// 21:11 3.34 M, 11:5 3.41 M, 12:4 4.11 M, one wave only 4.97 M.
 #ifndef DL_SHARE0
-#define DL_SHARE0 (DL_THREADS == 512 ? 10 : 6)
+#define DL_SHARE0 (DL_THREADS == 512 ? 21 : 6)
 #endif
 #ifndef DL_SHARE1
-#define DL_SHARE1 (DL_THREADS == 512 ? 6 : 5)
+#define DL_SHARE1 (DL_THREADS == 512 ? 11 : 5)
 #endif
 #ifndef DL_SHARE2
 #define DL_SHARE2 (DL_THREADS == 512 ? 0 : 5)
@@ -323,6 +324,16 @@ __device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lan
     const float4* wrp = reinterpret_cast<const float4*>(v.vec + 64 * hh);
     const float4* wdp = reinterpret_cast<const float4*>(v.vec + HID + 64 * hh);
     const float4* Wp = reinterpret_cast<const float4*>(v.W) + (64 * hh * 32 + c);
+    if (!EQUIV) {
+        // zero the aggregate rows of the atoms whose FIRST pair lies in this wave's range: every row is zeroed exactly
+        // once, by the first wave that can touch it, in that wave's own program order - no workgroup barrier needed
+        const int r0 = (32 * t_begin + nb - 1) / nb;
+        const int r1 = min((32 * t_end - 1) / nb, nb - 1);
+        for (int row = r0; row <= r1; ++row) {
+            v.C[row * LDH + lane] = 0.0f;
+            v.C[row * LDH + 64 + lane] = 0.0f;
+        }
+    }
 
     for (int t = t_begin; t < t_end; ++t) {
         const int p = 32 * t + c;
@@ -583,9 +594,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     prof_event(pf, w, lane, 11);
     dma_wait();
     lds_barrier();                         // P, Q, W2', vectors in place; every read of H (v.C) done
-    for (int e = tid; e < nb * LDH; e += THREADS) v.C[e] = 0.0f;
-    lds_barrier();
-    prof_event(pf, w, lane, 12);
+    prof_event(pf, w, lane, 12);           // (the aggregate rows are zeroed inside edge_phase, by the wave that starts them)
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
     sp = edge_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, accs, inv_pow2(accs));
