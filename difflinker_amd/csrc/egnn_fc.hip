@@ -47,6 +47,9 @@ constexpr int THREADS = DL_THREADS;
 constexpr int NWAVES = THREADS / 64;
 constexpr int GWAVES = 8;
 constexpr int GTHREADS = 64 * GWAVES;
+// helper-wave builds run three waves per SIMD = 168 VGPRs per lane: the node phases then hold ONE weight fragment (64
+// VGPRs) at a time and request it at the point of use (no cross-phase prefetch), which keeps them free of spills
+constexpr bool LEAN = NWAVES > GWAVES;
 __device__ __forceinline__ bool grid_wave(int w) { return NWAVES == GWAVES || w < GWAVES; }
 static_assert(THREADS == 512 || THREADS == 768, "8 grid waves + 0 or 4 helper waves");
 // pair-tile shares of the waves sharing a SIMD (w, w+4[, w+8]), oldest first: the older wave wins the issue
@@ -588,6 +591,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     if (grid_wave(w)) {
         // first-layer projections P,Q (fragments prefetched: `pw`; the W2' image is arriving by DMA)
         const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
+        if (LEAN) pw.bf = load_bfrag(g + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
         const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
         if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
     }
@@ -628,8 +632,9 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     if (active) {
         // fragments requested at the point of use: issued earlier they do not fit beside the h tile, and the register
         // allocator then waits for them just to spill them (measured: early prefetch 3.48-3.53 M ticks, this 3.38 M)
-        const BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
-        const BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+        BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
+        BFrag b3b;
+        if (!LEAN) b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
         const float b3 = vecs[4 * HID + 32 * nt + c];
         float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
         if (PREC == 1) {
@@ -640,7 +645,8 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
         floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
         const int arow = min(32 * mt + c, nb - 1);
         gemm_k128<PREC>(acc, v.A, arow, hh, b3a, s1);
-        b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);          // for layer 2, under layer 1's second GEMM
+        if (LEAN) b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+        else b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);    // for layer 2, under layer 1's second GEMM
         gemm_k128<PREC>(acc, v.C, arow, hh, b3b, s2);
         float tmax = 0.0f;
 #pragma unroll
@@ -655,8 +661,9 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     prof_event(pf, w, lane, 15);
     lds_barrier();
     // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
-    if (grid_wave(w)) load_next(pw, nx, w, lane);                  // the next pass's projection fragments, under layer 2
+    if (!LEAN && grid_wave(w)) load_next(pw, nx, w, lane);         // the next pass's projection fragments, under layer 2
     if (active) {
+        if (LEAN) b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
         const float b4 = vecs[5 * HID + 32 * nt + c];
         float s_t = 1.0f, inv = 1.0f;
         if (PREC == 1) { s_t = scale_for(__uint_as_float(v.fmax[FM_T])); inv = inv_pow2(s_t * sc[4]); }
@@ -701,6 +708,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     if (grid_wave(w)) {
         const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
         const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
+        if (LEAN) pw.bf = load_bfrag(e + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
         const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
         if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
     }
@@ -717,7 +725,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     // ---- back: coordinate update (lane indices re-derived, see lane_ids)
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane;
-    if (grid_wave(w)) load_next(pw, nx, w, lane);                  // next block's first pass, under the reduction
+    if (!LEAN && grid_wave(w)) load_next(pw, nx, w, lane);         // next block's first pass, under the reduction
     lds_barrier();
     if (grid_wave(w)) stage_next(v, nx, w, tid);
     spill_publish(v, sp, w, lane, true);
@@ -760,7 +768,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     if (grid_wave(w)) {                                             // first pass's weights (v.W, v.vec are free here)
         const NextPass first = {wp + OFF_BLOCKS, false};
         stage_next(v, first, w, tid);
-        load_next(pw, first, w, lane);
+        if (!LEAN) load_next(pw, first, w, lane);
     }
 
     // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
