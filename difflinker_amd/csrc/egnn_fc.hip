@@ -110,15 +110,17 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     return v;
 }
 
-// Optional phase timeline (diagnostics, dl_set_profile_buffer): lane 0 of every wave of block 0 logs
-// (tag, s_memtime) pairs into buf[wave][event][2]; buf == nullptr (the normal case) costs one
-// wave-uniform branch per phase.
+// Optional phase timeline (diagnostics builds only: -DDL_PROFILE, scripts/phase_timeline.py): lane 0 of every wave of
+// block 0 logs (tag, s_memtime) pairs into buf[wave][event][2] (dl_set_profile_buffer).  Compiled out of the product
+// library: even a never-taken branch per phase keeps the buffer pointer and the event counter alive across the pair
+// loops, i.e. in scratch, and each of the ~110 sites per forward then pays a reload round trip.
 constexpr int PROF_MAX_EVENTS = 512;
 struct Prof {
     unsigned long long* buf;
     int n;
 };
 __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
+#ifdef DL_PROFILE
     if (pf.buf != nullptr && grid_wave(w)) {
         if (lane == 0 && pf.n < PROF_MAX_EVENTS) {
             unsigned long long* e = pf.buf + (size_t(w) * PROF_MAX_EVENTS + pf.n) * 2;
@@ -127,6 +129,9 @@ __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
         }
         pf.n++;
     }
+#else
+    (void)pf; (void)w; (void)lane; (void)tag;
+#endif
 }
 
 // ---- f16x3 path (PREC 1): every fp32 operand of a 128-wide contraction is scaled by a power of two into the
@@ -1185,7 +1190,11 @@ void pack_vec(float* dst, const float* src, int stride, double scale) {
 extern "C" {
 
 int32_t dl_abi_version(void) { return DL_ABI_VERSION; }
+#ifdef DL_PROFILE
 int32_t dl_profile_max_events(void) { return PROF_MAX_EVENTS; }
+#else
+int32_t dl_profile_max_events(void) { return 0; }      // the phase timeline exists in -DDL_PROFILE builds only
+#endif
 void dl_set_profile_buffer(void* device_buf) { g_prof_buf = static_cast<unsigned long long*>(device_buf); }
 int32_t dl_last_hip_error(void) { return g_last_hip; }
 int32_t dl_max_atoms(void) { return NMAX; }

@@ -181,8 +181,9 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* s
 int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, int32_t B, int32_t N, int32_t nf, int32_t draw0,
                        int32_t n_draws, float* noise_x, float* noise_h, void* stream);
 
-/* Diagnostics: when set (device uint64 [8 waves][dl_profile_max_events()][2], or NULL to disable), the
- * first workgroup of the next launches logs (phase tag, shader clock) pairs of its first forward. */
+/* Diagnostics (libraries built with -DDL_PROFILE only; dl_profile_max_events() returns 0 otherwise): when set
+ * (device uint64 [8 waves][dl_profile_max_events()][2], or NULL to disable), the first workgroup of the next
+ * launches logs (phase tag, shader clock) pairs of its first forward. */
 void dl_set_profile_buffer(void* device_buf);
 int32_t dl_profile_max_events(void);
 

@@ -17,7 +17,16 @@ ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--layers', type=int, default=6)
 a = ap.parse_args()
 
+import subprocess
 import __graft_entry__ as entry
+# the phase log is compiled out of the product library: build (or reuse) a -DDL_PROFILE copy under build/
+if 'DIFFLINKER_HIP_LIB' not in os.environ:
+    prof_lib = os.path.join(ROOT, 'build', 'libdifflinker_hip_profile.so')
+    if not os.path.exists(prof_lib) or any(os.path.getmtime(src) > os.path.getmtime(prof_lib) for src in entry.HIP_SOURCES):
+        os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
+        subprocess.run([entry.HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
+                        '-DDL_PROFILE', '-I', os.path.join(ROOT, 'include')] + entry.HIP_SOURCES + ['-o', prof_lib], check=True)
+    os.environ['DIFFLINKER_HIP_LIB'] = prof_lib
 entry.build()
 from difflinker_amd import Dynamics, synthetic, _lib
 
@@ -46,6 +55,7 @@ torch.cuda.synchronize()
 print(f'forward (B={B}, n={a.n}, L={a.layers}): {ev0.elapsed_time(ev1) / 5:.3f} ms')
 
 maxev = lib.dl_profile_max_events()
+assert maxev > 0, 'this library was built without -DDL_PROFILE'
 buf = torch.zeros((8, maxev, 2), dtype=torch.int64, device=dev)
 lib.dl_set_profile_buffer(ctypes.c_void_p(buf.data_ptr()))
 dyn.forward(**args)
