@@ -56,7 +56,7 @@ EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_stri
            'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
            'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
            'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
-           'dl_size_gnn_forward', 'dl_philox_fill')
+           'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large')
 
 _lib = None
 
@@ -101,6 +101,8 @@ def load():
     lib.dl_pocket_workspace_bytes.argtypes = [i32, i32]
     lib.dl_egnn_forward_pocket.restype = i32
     lib.dl_egnn_forward_pocket.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+    lib.dl_egnn_forward_fc_large.restype = i32
+    lib.dl_egnn_forward_fc_large.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dl_sample_chain_fc.restype = i32
     lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
     lib.dl_philox_fill.restype = i32

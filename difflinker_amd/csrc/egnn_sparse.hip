@@ -28,13 +28,14 @@ constexpr int EDGE_THREADS = 256;
 struct PkDims {
     int B, N, V;                         // V = B*N padded atoms
     int nf, ctx, fin, D;
-    int graph_type;                      // 0: '4A', 1: 'FC-4A', 2: 'FC-10A-4A'
+    int graph_type;                      // 0: '4A', 1: 'FC-4A', 2: 'FC-10A-4A', 3: fully connected with an int8 edge mask
+    const int8_t* emask;                 // graph_type 3: [B,N,N] mask values (0: no edge; the value weights the message)
     float norm_constant;
 };
 
 // workspace carve-up (all offsets in bytes, 256-B aligned)
 struct PkWs {
-    float *H, *P, *Q, *X, *X0, *partial, *partialx, *pmax, *qmax;
+    float *H, *P, *Q, *X, *X0, *partial, *partialx, *pmax, *qmax, *wgt;
     int *flags, *ntile, *tile_off, *tile_row, *col, *total;
     size_t bytes;
 };
@@ -61,6 +62,7 @@ inline PkWs carve(void* base, int B, int N) {
     w.total = reinterpret_cast<int*>(take(256));
     w.tile_row = reinterpret_cast<int*>(take(TMAX * 4));
     w.col = reinterpret_cast<int*>(take(TMAX * 32 * 4));
+    w.wgt = reinterpret_cast<float*>(take(TMAX * 32 * 4));     // per-edge weight (graph_type 3), 0 on padding
     w.partial = reinterpret_cast<float*>(take(TMAX * HID * 4));
     w.partialx = reinterpret_cast<float*>(take(TMAX * 16));
     w.bytes = off;
@@ -90,9 +92,12 @@ __global__ void pk_init_kernel(PkDims d, PkWs w, const float* __restrict__ wp, c
         w.X0[4 * v + f] = xv;
     }
     if (f == 4) {
-        // fragment-only / pocket-only masks are the last two context channels (egnn.py:486-487)
-        const bool lig = real && ((linker_mask[v] != 0.0f) || (context[size_t(v) * d.ctx + d.ctx - 2] != 0.0f));
-        const bool pock = real && (context[size_t(v) * d.ctx + d.ctx - 1] != 0.0f);
+        bool lig = false, pock = false;
+        if (d.graph_type != 3) {
+            // fragment-only / pocket-only masks are the last two context channels (egnn.py:486-487)
+            lig = real && ((linker_mask[v] != 0.0f) || (context[size_t(v) * d.ctx + d.ctx - 2] != 0.0f));
+            pock = real && (context[size_t(v) * d.ctx + d.ctx - 1] != 0.0f);
+        }
         w.flags[v] = (real ? F_REAL : 0) | (lig ? F_LIG : 0) | (pock ? F_POCK : 0);
     }
     float acc = wp[OFF_EMB_B + f];
@@ -131,20 +136,36 @@ __global__ void pk_edges_kernel(PkDims d, PkWs w) {
         const int jn = j0 + lane;
         const int u = b * d.N + jn;
         bool adj = false;
-        if (jn < d.N && u != v) {
+        float wt = 1.0f;
+        if (d.graph_type == 3) {
+            // the reference's dense edge list with its mask (egnn.py:449-466 + datasets.py:366-369): every pair of the
+            // molecule whose int8 mask value is non-zero - the diagonal included (value -2) - weighted by that value
+            if (jn < d.N) {
+                const int mv = d.emask[(size_t(b) * d.N + (v - b * d.N)) * d.N + jn];
+                adj = mv != 0;
+                wt = float(mv);
+            }
+        } else if (jn < d.N && u != v) {
             const float4 xj = *reinterpret_cast<const float4*>(w.X + 4 * u);
             const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
             adj = pk_adjacent(d.graph_type, fi, w.flags[u], dx * dx + dy * dy + dz * dz);
         }
         const unsigned long long bal = __ballot(adj);
-        if (FILL && adj) w.col[size_t(base_tile) * 32 + count + __popcll(bal & ((1ull << lane) - 1ull))] = u;
+        if (FILL && adj) {
+            const size_t slot = size_t(base_tile) * 32 + count + __popcll(bal & ((1ull << lane) - 1ull));
+            w.col[slot] = u;
+            w.wgt[slot] = wt;
+        }
         count += __popcll(bal);
     }
     const int nt = (count + 31) >> 5;
     if (!FILL) {
         if (lane == 0) w.ntile[v] = nt;
     } else {
-        for (int e = count + lane; e < nt * 32; e += 64) w.col[size_t(base_tile) * 32 + e] = -1;   // padding
+        for (int e = count + lane; e < nt * 32; e += 64) {                                         // padding
+            w.col[size_t(base_tile) * 32 + e] = -1;
+            w.wgt[size_t(base_tile) * 32 + e] = 0.0f;
+        }
         if (lane < nt) w.tile_row[base_tile + lane] = v;
         for (int k = 64 + lane; k < nt; k += 64) w.tile_row[base_tile + k] = v;
     }
@@ -357,7 +378,7 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
 //    EQUIV = false: partial[t][f] = sum over the tile's edges of u2[f]            (edge_mask = None: weight 1)
 //    EQUIV = true : partialx[t]   = sum over the tile's edges of cdiff * (w7'.u2)
 // ---------------------------------------------------------------------------------------------------
-template <bool EQUIV, int PREC>
+template <bool EQUIV, int PREC, bool WEIGHTED>
 __global__ void __launch_bounds__(EDGE_THREADS)
 pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */,
                const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index) {
@@ -483,7 +504,9 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const float m = (acc_row(reg, hh) < nvalid) ? 1.0f : 0.0f;   // padding edges sit at the tile's end
+                // padding edges sit at the tile's end; WEIGHTED: the int8 mask value of the edge (0 on padding)
+                const float m = WEIGHTED ? w.wgt[size_t(t) * 32 + acc_row(reg, hh)]
+                                         : ((acc_row(reg, hh) < nvalid) ? 1.0f : 0.0f);
                 s0 = fmaf(m, silu_u(acc0[reg]), s0);
                 s1 = fmaf(m, silu_u(acc1[reg]), s1);
                 s2 = fmaf(m, silu_u(acc2[reg]), s2);
@@ -510,7 +533,8 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 s_own = (reg == my_reg) ? (want_hi ? hi : lo) : s_own;
             }
             const float den = sqrtf(r + 1e-8f) + d.norm_constant;   // coord2diff, egnn.py:299-300
-            const float f = (hh == 0 && valid) ? s_own : 0.0f;
+            float f = (hh == 0 && valid) ? s_own : 0.0f;
+            if (WEIGHTED) f *= w.wgt[size_t(t) * 32 + c];
             const float ax = half32_allsum((dx / den) * f);
             const float ay = half32_allsum((dy / den) * f);
             const float az = half32_allsum((dz / den) * f);
@@ -576,21 +600,21 @@ size_t dl_pocket_workspace_bytes(int32_t B, int32_t N) {
     return carve(nullptr, B, N).bytes;
 }
 
-int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, const float* xh,
-                               const float* t, int32_t t_is_scalar, const int8_t* node_mask,
-                               const float* linker_mask, const float* context, float* out, int32_t* nan_flags,
-                               void* workspace, size_t workspace_bytes, void* stream_) {
-    if (!m || !xh || !t || !node_mask || !linker_mask || !context || !out || !nan_flags || !workspace)
-        return DL_ERR_BAD_ARG;
-    if (B < 0 || N < 1 || graph_type < 0 || graph_type > 2) return DL_ERR_BAD_ARG;
-    if (m->cfg.context_node_nf < 2) return DL_ERR_BAD_ARG;                      // needs the fragment/pocket channels
+}  // extern "C"
+
+namespace {
+int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, const float* xh, const float* t,
+                   int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask, const int8_t* emask,
+                   const float* context, float* out, int32_t* nan_flags, void* workspace, size_t workspace_bytes,
+                   void* stream_) {
     if (B == 0) return DL_OK;
     if (workspace_bytes < carve(nullptr, B, N).bytes) return DL_ERR_BAD_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const ModelDims md = dims_of(m);
     PkDims d;
     d.B = B; d.N = N; d.V = B * N; d.nf = md.nf; d.ctx = md.ctx; d.fin = md.fin; d.D = 3 + md.nf;
-    d.graph_type = graph_type; d.norm_constant = md.norm_constant;
+    d.graph_type = graph_type; d.norm_constant = md.norm_constant; d.emask = emask;
+    const bool weighted = graph_type == 3;
     const PkWs w = carve(workspace, B, N);
     const float* wp = m->d_pack;
     const int V = d.V;
@@ -611,11 +635,15 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
     };
     auto edge = [&](bool equiv, const float* wimg, const float* vecs, const float* sc, int sw) {
         if (!equiv) {
-            if (f16) hipLaunchKernelGGL((pk_edge_kernel<false, 1>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else hipLaunchKernelGGL((pk_edge_kernel<false, 0>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            if (f16 && weighted) hipLaunchKernelGGL((pk_edge_kernel<false, 1, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else if (f16) hipLaunchKernelGGL((pk_edge_kernel<false, 1, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else if (weighted) hipLaunchKernelGGL((pk_edge_kernel<false, 0, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else hipLaunchKernelGGL((pk_edge_kernel<false, 0, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
         } else {
-            if (f16) hipLaunchKernelGGL((pk_edge_kernel<true, 1>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else hipLaunchKernelGGL((pk_edge_kernel<true, 0>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            if (f16 && weighted) hipLaunchKernelGGL((pk_edge_kernel<true, 1, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else if (f16) hipLaunchKernelGGL((pk_edge_kernel<true, 1, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else if (weighted) hipLaunchKernelGGL((pk_edge_kernel<true, 0, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            else hipLaunchKernelGGL((pk_edge_kernel<true, 0, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
         }
     };
     for (int blk = 0; blk < md.n_layers; ++blk) {
@@ -638,6 +666,32 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
     }
     hipLaunchKernelGGL(pk_out_kernel, dim3((V * d.D + 255) / 256), dim3(256), 0, st, d, w, wp, out, nan_flags);
     return ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, const float* xh,
+                               const float* t, int32_t t_is_scalar, const int8_t* node_mask,
+                               const float* linker_mask, const float* context, float* out, int32_t* nan_flags,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !xh || !t || !node_mask || !linker_mask || !context || !out || !nan_flags || !workspace)
+        return DL_ERR_BAD_ARG;
+    if (B < 0 || N < 1 || graph_type < 0 || graph_type > 2) return DL_ERR_BAD_ARG;
+    if (m->cfg.context_node_nf < 2) return DL_ERR_BAD_ARG;                      // needs the fragment/pocket channels
+    return run_sparse(m, B, N, graph_type, xh, t, t_is_scalar, node_mask, linker_mask, nullptr, context, out, nan_flags,
+                      workspace, workspace_bytes, stream);
+}
+
+int32_t dl_egnn_forward_fc_large(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
+                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
+                                 const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!m || !xh || !t || !node_mask || !edge_mask || !out || !nan_flags || !workspace) return DL_ERR_BAD_ARG;
+    if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
+    if (B < 0 || N < 1) return DL_ERR_BAD_ARG;
+    return run_sparse(m, B, N, 3, xh, t, t_is_scalar, node_mask, linker_mask, edge_mask, context, out, nan_flags, workspace,
+                      workspace_bytes, stream);
 }
 
 }  // extern "C"

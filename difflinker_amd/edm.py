@@ -228,7 +228,7 @@ class EDM(torch.nn.Module):
             keep_frames = self.T
         else:
             assert keep_frames <= self.T
-        if not self._fused_ok():
+        if not self._fused_ok() or not self.dynamics.fits_lds(node_mask):
             if noise_bank is None and self.noise_source == 'philox':
                 noise_bank = self.philox_noise_bank(x.size(0), x.size(1), x.device, mol_offset)
             return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,

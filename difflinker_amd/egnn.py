@@ -236,7 +236,14 @@ class Dynamics(nn.Module):
     def _f32(t):
         return None if t is None else t.to(torch.float32).contiguous()
 
-    def _launch_forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+    def fits_lds(self, node_mask):
+        """True when every molecule fits the LDS-resident kernels (<= ``dl_max_atoms()`` real atoms).  Bigger batches run
+        on the HBM-resident per-pass kernels (``dl_egnn_forward_fc_large``): same numbers, several times slower."""
+        n_nodes = node_mask.shape[1]
+        limit = _lib.load().dl_max_atoms()
+        return n_nodes <= limit or int(node_mask.reshape(node_mask.shape[0], n_nodes).ne(0).sum(1).max()) <= limit
+
+    def _launch_forward(self, t, xh, node_mask, linker_mask, edge_mask, context, large=False):
         lib = _lib.load()
         dev = xh.device
         bs, n_nodes = xh.shape[0], xh.shape[1]
@@ -255,10 +262,22 @@ class Dynamics(nn.Module):
         flags = torch.empty(bs, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _lib.check(lib.dl_egnn_forward_fc(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
-                                              _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
-                                              _lib.ptr(out), _lib.ptr(flags), ctypes.c_void_p(stream)),
-                       'dl_egnn_forward_fc')
+            if not large:
+                _lib.check(lib.dl_egnn_forward_fc(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
+                                                  _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
+                                                  _lib.ptr(out), _lib.ptr(flags), ctypes.c_void_p(stream)),
+                           'dl_egnn_forward_fc')
+            else:
+                if em is None:
+                    raise ValueError('molecules beyond the LDS-resident limit need the edge_mask tensor')
+                need = int(lib.dl_pocket_workspace_bytes(bs, n_nodes))
+                ws = getattr(self, '_large_ws', None)
+                if ws is None or ws.numel() < need or ws.device != dev:
+                    ws = self._large_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                _lib.check(lib.dl_egnn_forward_fc_large(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
+                                                        _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
+                                                        _lib.ptr(out), _lib.ptr(flags), _lib.ptr(ws), need,
+                                                        ctypes.c_void_p(stream)), 'dl_egnn_forward_fc_large')
         return out, flags
 
     def _raise_on_flags(self, flags):
@@ -277,7 +296,8 @@ class Dynamics(nn.Module):
         Returns eps_hat (B, N, 3 + nf) = cat[vel, h_final]; raises ``utils.FoundNaNException``.
         """
         assert self.graph_type == 'FC'
-        out, flags = self._launch_forward(t, xh, node_mask, linker_mask, edge_mask, context)
+        out, flags = self._launch_forward(t, xh, node_mask, linker_mask, edge_mask, context,
+                                          large=not self.fits_lds(node_mask))
         self._raise_on_flags(flags)
         if self.centering:                                     # inpainting only (egnn.py:444-445)
             nm = node_mask.reshape(xh.shape[0], xh.shape[1], 1).to(out.dtype)

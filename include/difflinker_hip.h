@@ -132,6 +132,17 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
                                float* out, int32_t* nan_flags, void* workspace, size_t workspace_bytes,
                                void* stream);
 
+/* Dynamics.forward (src/egnn.py:374-447) for fully-connected graphs of ANY size: the HBM-resident per-pass kernels of
+ * the pocket path run on the reference's own dense edge list — every pair whose int8 edge_mask value is non-zero, the
+ * diagonal included (value -2, src/datasets.py:366-369), each message weighted by that value.  Use it for batches with a
+ * molecule of more than dl_max_atoms() atoms (dl_egnn_forward_fc flags those with bit 2); several times slower than
+ * the LDS-resident kernel.  Arguments as dl_egnn_forward_fc (edge_mask required, linker_mask may be NULL);
+ * workspace: dl_pocket_workspace_bytes(B, N). */
+int32_t dl_egnn_forward_fc_large(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
+                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
+                                 const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-step scalars of the reverse process, computed by the host exactly as the reference does
  * (src/edm.py:180-185,199,202): one row per reverse step, in execution order (s = T-1 ... 0). */
 typedef struct dl_step_coef {

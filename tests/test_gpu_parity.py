@@ -238,12 +238,53 @@ def test_nan_raises_found_nan_exception_with_index_sets():
     assert ei.value.only_h_nan_idx == eo.value.only_h_nan_idx
 
 
-def test_too_many_atoms_is_an_error_not_a_fallback():
-    nf = 9
-    dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=14)
-    inp, z, t = ragged_inputs([56, 10], [5, 2], nf, seed=11)
-    with pytest.raises(ValueError, match='real atoms'):
-        run_hip_forward(dyn, inp, z, t)
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+@pytest.mark.parametrize('sizes,linkers', [([56, 10], [5, 2]), ([70, 33, 64], [9, 4, 12])])
+def test_molecules_beyond_the_lds_limit_run_on_the_hbm_resident_kernels(sizes, linkers, precision):
+    """More than dl_max_atoms() atoms: Dynamics.forward switches to dl_egnn_forward_fc_large (the pocket path's
+    per-pass kernels on the dense masked edge list, self loops weighted -2 like the int8 mask says) - same numbers."""
+    nf, L = 9, 2
+    dyn, sd, cfg = make_dynamics(nf, 1, L, seed=14, precision=precision)
+    inp, z, t = ragged_inputs(sizes, linkers, nf, seed=11)
+    assert not dyn.fits_lds(inp['node_mask'].to(dev()))
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'],
+                                       inp['context'])
+    out = run_hip_forward(dyn, inp, z, t)
+    ev, eh = report(f'large fwd sizes={sizes} {precision}', out, ref, z)
+    nm = inp['node_mask'].float()
+    assert float((out * (1 - nm)).abs().max()) == 0.0
+    assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
+    assert torch.equal(out, run_hip_forward(dyn, inp, z, t)), 'bitwise repeatable'
+    # the same molecules that DO fit give the same answer on either path (first 10-atom molecule of the small case)
+    if sizes == [56, 10]:
+        small, zs, ts = ragged_inputs([10, 12], [2, 3], nf, seed=12)
+        a = run_hip_forward(dyn, small, zs, ts)
+        d = dev()
+        b, _ = dyn._launch_forward(ts.to(d), zs.to(d), small['node_mask'].to(d), small['linker_mask'].to(d),
+                                   small['edge_mask'].to(d), small['context'].to(d), large=True)
+        assert rel_l2(b.cpu(), a) <= 2e-6
+
+
+def test_chain_with_a_large_molecule_uses_the_host_loop():
+    """A batch with a > 55-atom molecule: EDM.sample_chain falls back from the fused launch to the host-driven loop of
+    HIP forwards + fused sampler tails; still the reference's numbers."""
+    from difflinker_amd import EDM
+    nf, T, keep = 8, 6, 2
+    dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=33)
+    inp, _, _ = ragged_inputs([58, 12], [6, 3], nf, seed=34)
+    B, N = inp['x'].shape[:2]
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+              loss_type='l2', norm_values=[1, 4, 10]).to(dev())
+    edm.T = T
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=35)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                            inp['edge_mask'], inp['context'], bank, keep_frames=keep)
+    g = {k: v.to(dev()) for k, v in inp.items()}
+    got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
+                           g['context'], keep_frames=keep, noise_bank=bank.stacked()).cpu()
+    check_chain('chain with a 58-atom molecule', got, want, inp)
 
 
 def test_sampler_step_kernel_matches_oracle_arithmetic():
