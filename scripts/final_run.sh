@@ -8,3 +8,4 @@ timeout 300 python bench.py --noise philox --no-cpu-baseline > gpurun_out/bench_
 timeout 300 python bench.py --uniform-size --no-cpu-baseline --steps 2 > gpurun_out/bench_uniform_d.log 2>&1; tail -1 gpurun_out/bench_uniform_d.log | cut -c1-300
 timeout 600 python bench.py --config C4 --steps 2 --warmup 1 > gpurun_out/bench_c4_d.log 2>&1; tail -1 gpurun_out/bench_c4_d.log | cut -c1-300
 bash scripts/profile_gpu.sh r01d > gpurun_out/profile_r01d.log 2>&1; tail -3 gpurun_out/profile_r01d.log
+timeout 300 python scripts/phase_timeline.py --n 50 > gpurun_out/timeline_final.log 2>&1; grep -E "^forward" gpurun_out/timeline_final.log
