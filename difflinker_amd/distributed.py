@@ -76,5 +76,11 @@ def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=N
         noise_bank = edm.draw_noise_bank(bs, n, inputs['x'].device)
     if noise_bank is not None:
         kw['noise_bank'] = (noise_bank[0][:, lo:hi].contiguous(), noise_bank[1][:, lo:hi].contiguous())
-    chain = edm.sample_chain(keep_frames=keep_frames, **local, **kw)
+    pinned = getattr(edm, 'coef_batch', None)
+    if pinned is None:
+        edm.coef_batch = bs                  # per-step scalars of the WHOLE batch (see EDM.coef_batch)
+    try:
+        chain = edm.sample_chain(keep_frames=keep_frames, **local, **kw)
+    finally:
+        edm.coef_batch = pinned
     return all_gather_frames(chain, bs, group) if gather else chain

@@ -52,6 +52,10 @@ class EDM(torch.nn.Module):
         # draw) and therefore independent of the batch split; noise_seed advances by one per sampled chain.
         self.noise_source = 'torch'
         self.noise_seed = 0
+        # batch size the per-step scalars are evaluated for (None: the batch at hand).  The reference evaluates them on
+        # [B,1] tensors and PyTorch's CPU kernels round differently on their vector (B >= 16) and scalar paths, so a
+        # shard of a batch pins this to the size of the whole batch to sample exactly what the unsharded call would.
+        self.coef_batch = None
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError('EDM.forward is the training loss (edm.py:41-124): out of scope of the '
@@ -126,6 +130,8 @@ class EDM(torch.nn.Module):
         transcendentals round differently on its vectorised and scalar paths, and the cancellation in
         sigma^2_{t|s} amplifies that to ~2e-5, so the shape is part of the parity contract.
         Returns (coefs [T,4] = (t, alpha_ts, c_eps, sigma), (inv_alpha0, sigma0, sigma_x))."""
+        if self.coef_batch is not None:
+            batch_size = self.coef_batch
         key = (self.T, int(batch_size))
         cached = getattr(self, '_coef_cache', None)
         if cached is not None and cached[0] == key and cached[1] == self.gamma.gamma._version:
