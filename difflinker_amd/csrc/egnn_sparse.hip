@@ -407,47 +407,95 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     const int ntiles = w.total[0];
     const int gw = blockIdx.x * (EDGE_THREADS / 64) + wv, GW = gridDim.x * (EDGE_THREADS / 64);
 
-    for (int t = gw; t < ntiles; t += GW) {
-        const int i = w.tile_row[t];
-        const int jraw = w.col[size_t(t) * 32 + c];
+    // Software-pipelined tile loop.  Every global access of a tile is a dependent chain (tile -> atoms -> coordinates ->
+    // rows of P / Q) and the vector-memory counter retires in order, so loading at the point of use costs ~20 serialized
+    // L2 round trips per tile (measured: 15 K cycles per tile against 7.4 K on the LDS-resident path).  Instead:
+    //   * the geometry (i, j, r, d0, bound) of the NEXT tile is fetched while this tile computes,
+    //   * this tile's 32 Q rows are requested in one burst at the top (16 x 16 B per lane, consumed slab by slab),
+    //   * the P row (one receiving atom per tile) goes through a per-wave LDS stage instead of 16 more loads per lane.
+    __shared__ __attribute__((aligned(16))) float Pst[EDGE_THREADS / 64][HID];
+    float* pst = Pst[wv];
+    int t = gw;
+    int i = 0, jraw = -1;
+    float r = 0.0f, d0 = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, pqb = 0.0f;
+    if (t < ntiles) {
+        i = w.tile_row[t];
+        jraw = w.col[size_t(t) * 32 + c];
+        const int j0 = jraw >= 0 ? jraw : i;
+        const float4 xi = *reinterpret_cast<const float4*>(w.X + 4 * i);
+        const float4 xj = *reinterpret_cast<const float4*>(w.X + 4 * j0);
+        const float4 yi = *reinterpret_cast<const float4*>(w.X0 + 4 * i);
+        const float4 yj = *reinterpret_cast<const float4*>(w.X0 + 4 * j0);
+        dx = xi.x - xj.x; dy = xi.y - xj.y; dz = xi.z - xj.z;
+        const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
+        r = dx * dx + dy * dy + dz * dz;
+        d0 = ex * ex + ey * ey + ez * ez;
+        if (PREC == 1) pqb = w.pmax[i] + w.qmax[j0];
+    }
+    for (; t < ntiles; t += GW) {
         const bool valid = jraw >= 0;
         const int j = valid ? jraw : i;
         const int nvalid = __popcll(__ballot(valid)) >> 1;          // both halves hold the same 32 edges
-        const float4 xi = *reinterpret_cast<const float4*>(w.X + 4 * i);
-        const float4 xj = *reinterpret_cast<const float4*>(w.X + 4 * j);
-        const float4 yi = *reinterpret_cast<const float4*>(w.X0 + 4 * i);
-        const float4 yj = *reinterpret_cast<const float4*>(w.X0 + 4 * j);
-        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
-        const float r = dx * dx + dy * dy + dz * dz;
-        const float d0 = ex * ex + ey * ey + ez * ez;
+        // ---- (1) this tile's rows: P row -> LDS stage (first, so that waiting for it leaves the Q burst in flight)
+        const float2 p2 = *reinterpret_cast<const float2*>(w.P + size_t(i) * HID + 2 * lane);
+        float4 qv[16];
+        {
+            const float* Qrow = w.Q + size_t(j) * HID;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k = (PREC == 0) ? 64 * hh + 4 * q : 16 * (q >> 1) + 4 * (q & 1) + 8 * hh;
+                qv[q] = *reinterpret_cast<const float4*>(Qrow + k);
+            }
+        }
+        // ---- (2) the next tile's atoms
+        const int tn = t + GW;
+        const bool more = tn < ntiles;
+        int i_n = i, j_n = -1;
+        if (more) {
+            i_n = w.tile_row[tn];
+            j_n = w.col[size_t(tn) * 32 + c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        *reinterpret_cast<float2*>(pst + 2 * lane) = p2;
         floatx16 acc0, acc1, acc2, acc3;
+        float xn[12];                                              // next tile: xi, xj, yi, yj coordinates
+        float pq_n = 0.0f;
+        auto request_next_geometry = [&]() {
+            const int jn0 = j_n >= 0 ? j_n : i_n;
+            const float4 a = *reinterpret_cast<const float4*>(w.X + 4 * i_n);
+            const float4 b = *reinterpret_cast<const float4*>(w.X + 4 * jn0);
+            const float4 cc = *reinterpret_cast<const float4*>(w.X0 + 4 * i_n);
+            const float4 dd = *reinterpret_cast<const float4*>(w.X0 + 4 * jn0);
+            xn[0] = a.x; xn[1] = a.y; xn[2] = a.z; xn[3] = b.x; xn[4] = b.y; xn[5] = b.z;
+            xn[6] = cc.x; xn[7] = cc.y; xn[8] = cc.z; xn[9] = dd.x; xn[10] = dd.y; xn[11] = dd.z;
+            if (PREC == 1) pq_n = w.pmax[i_n] + w.qmax[jn0];
+        };
         if constexpr (PREC == 0) {
             float a[64];
             {
-                const float4* Pp = reinterpret_cast<const float4*>(w.P + size_t(i) * HID + 64 * hh);
-                const float4* Qp = reinterpret_cast<const float4*>(w.Q + size_t(j) * HID + 64 * hh);
+                const float4* Pp = reinterpret_cast<const float4*>(pst + 64 * hh);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
+                    const float4 P = Pp[q], Q = qv[q], wr = wrp[q], wd = wdp[q];
                     a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
                     a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
                     a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
                     a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
                 }
             }
+            request_next_geometry();
             acc0 = splat16(bias[0]); acc1 = splat16(bias[1]); acc2 = splat16(bias[2]); acc3 = splat16(bias[3]);
 #pragma unroll
-            for (int s = 0; s < 64; ++s) {
-                const float4 b = Wp[s * 32];
-                acc0 = mfma32(a[s], b.x, acc0);
-                acc1 = mfma32(a[s], b.y, acc1);
-                acc2 = mfma32(a[s], b.z, acc2);
-                acc3 = mfma32(a[s], b.w, acc3);
+            for (int s_ = 0; s_ < 64; ++s_) {
+                const float4 b = Wp[s_ * 32];
+                acc0 = mfma32(a[s_], b.x, acc0);
+                acc1 = mfma32(a[s_], b.y, acc1);
+                acc2 = mfma32(a[s_], b.z, acc2);
+                acc3 = mfma32(a[s_], b.w, acc3);
             }
         } else {
             // f16x3: |u| <= |y| <= max|P_i| + max|Q_j| + r*max|wr'| + d0*max|wd'|; the tile's largest bound sets the scale
-            float bound = w.pmax[i] + w.qmax[j] + r * sc[6] + d0 * sc[7];
+            float bound = pqb + r * sc[6] + d0 * sc[7];
             bound = fmaxf(bound, dpp_mov<0xB1>(bound));
             bound = fmaxf(bound, dpp_mov<0x4E>(bound));
             bound = fmaxf(bound, dpp_mov<0x141>(bound));
@@ -458,21 +506,21 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             }
             const float sa = scale_for(__builtin_amdgcn_readfirstlane(bound));   // wave-uniform (both halves hold the same pairs)
             const float accs = sa * sc[sw_index], inv = inv_pow2(accs);
-            acc0 = splat16(bias[0] * accs); acc1 = splat16(bias[1] * accs);
-            acc2 = splat16(bias[2] * accs); acc3 = splat16(bias[3] * accs);
+            // accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
+            acc0 = splat16(0.0f); acc1 = splat16(0.0f); acc2 = splat16(0.0f); acc3 = splat16(0.0f);
             const uint4* Wq = reinterpret_cast<const uint4*>(W) + lane;
-            const float* Pp = w.P + size_t(i) * HID + 8 * hh;
-            const float* Qp = w.Q + size_t(j) * HID + 8 * hh;
+            const float* Pp = pst + 8 * hh;
             const float* wrb = vec + 8 * hh;
             const float* wdb = vec + HID + 8 * hh;
 #pragma unroll
             for (int slab = 0; slab < 8; ++slab) {
+                if (slab == 4) request_next_geometry();
                 float us[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int k0 = 16 * slab + 4 * q;
                     const float4 P = *reinterpret_cast<const float4*>(Pp + k0);
-                    const float4 Q = *reinterpret_cast<const float4*>(Qp + k0);
+                    const float4 Q = qv[2 * slab + q];
                     const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
                     const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
                     us[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x))) * sa;
@@ -497,7 +545,8 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                acc0[reg] *= inv; acc1[reg] *= inv; acc2[reg] *= inv; acc3[reg] *= inv;
+                acc0[reg] = fmaf(acc0[reg], inv, bias[0]); acc1[reg] = fmaf(acc1[reg], inv, bias[1]);
+                acc2[reg] = fmaf(acc2[reg], inv, bias[2]); acc3[reg] = fmaf(acc3[reg], inv, bias[3]);
             }
         }
         if (!EQUIV) {
@@ -540,6 +589,15 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             const float az = half32_allsum((dz / den) * f);
             if (lane == 0) *reinterpret_cast<float4*>(w.partialx + size_t(t) * 4) = make_float4(ax, ay, az, 0.0f);
         }
+        // ---- the prefetched geometry becomes the current one
+        i = i_n; jraw = j_n;
+        dx = xn[0] - xn[3]; dy = xn[1] - xn[4]; dz = xn[2] - xn[5];
+        {
+            const float ex = xn[6] - xn[9], ey = xn[7] - xn[10], ez = xn[8] - xn[11];
+            r = dx * dx + dy * dy + dz * dz;
+            d0 = ex * ex + ey * ey + ez * ez;
+        }
+        pqb = pq_n;
     }
 }
 
