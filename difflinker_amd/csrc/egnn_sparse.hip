@@ -379,7 +379,7 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
 //    EQUIV = true : partialx[t]   = sum over the tile's edges of cdiff * (w7'.u2)
 // ---------------------------------------------------------------------------------------------------
 template <bool EQUIV, int PREC, bool WEIGHTED>
-__global__ void __launch_bounds__(EDGE_THREADS)
+__global__ void __launch_bounds__(EDGE_THREADS, 2)     // two waves per SIMD (two workgroups per CU): <= 256 VGPR + AGPR
 pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */,
                const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index) {
     __shared__ __attribute__((aligned(16))) float W[UNIT];
@@ -432,22 +432,23 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         d0 = ex * ex + ey * ey + ez * ez;
         if (PREC == 1) pqb = w.pmax[i] + w.qmax[j0];
     }
+    // rows of the CURRENT tile (requested one tile ahead): the receiving atom's P row and the 32 senders' Q rows
+    float2 p2 = make_float2(0.0f, 0.0f);
+    float4 qv[16];
+    auto request_rows = [&](int ii, int jj, float2& pr, float4 (&qr)[16]) {
+        pr = *reinterpret_cast<const float2*>(w.P + size_t(ii) * HID + 2 * lane);
+        const float* Qrow = w.Q + size_t(jj) * HID;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = (PREC == 0) ? 64 * hh + 4 * q : 16 * (q >> 1) + 4 * (q & 1) + 8 * hh;
+            qr[q] = *reinterpret_cast<const float4*>(Qrow + k);
+        }
+    };
+    if (t < ntiles) request_rows(i, jraw >= 0 ? jraw : i, p2, qv);
     for (; t < ntiles; t += GW) {
         const bool valid = jraw >= 0;
-        const int j = valid ? jraw : i;
         const int nvalid = __popcll(__ballot(valid)) >> 1;          // both halves hold the same 32 edges
-        // ---- (1) this tile's rows: P row -> LDS stage (first, so that waiting for it leaves the Q burst in flight)
-        const float2 p2 = *reinterpret_cast<const float2*>(w.P + size_t(i) * HID + 2 * lane);
-        float4 qv[16];
-        {
-            const float* Qrow = w.Q + size_t(j) * HID;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int k = (PREC == 0) ? 64 * hh + 4 * q : 16 * (q >> 1) + 4 * (q & 1) + 8 * hh;
-                qv[q] = *reinterpret_cast<const float4*>(Qrow + k);
-            }
-        }
-        // ---- (2) the next tile's atoms
+        // ---- (1) the next tile's atoms (its rows and geometry are requested mid-body, once these have arrived)
         const int tn = t + GW;
         const bool more = tn < ntiles;
         int i_n = i, j_n = -1;
@@ -456,7 +457,9 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             j_n = w.col[size_t(tn) * 32 + c];
         }
         __builtin_amdgcn_sched_barrier(0);
-        *reinterpret_cast<float2*>(pst + 2 * lane) = p2;
+        *reinterpret_cast<float2*>(pst + 2 * lane) = p2;            // this tile's P row -> per-wave LDS stage
+        float2 p2n = make_float2(0.0f, 0.0f);
+        float4 qn[16];
         floatx16 acc0, acc1, acc2, acc3;
         float xn[12];                                              // next tile: xi, xj, yi, yj coordinates
         float pq_n = 0.0f;
@@ -469,6 +472,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             xn[0] = a.x; xn[1] = a.y; xn[2] = a.z; xn[3] = b.x; xn[4] = b.y; xn[5] = b.z;
             xn[6] = cc.x; xn[7] = cc.y; xn[8] = cc.z; xn[9] = dd.x; xn[10] = dd.y; xn[11] = dd.z;
             if (PREC == 1) pq_n = w.pmax[i_n] + w.qmax[jn0];
+            request_rows(i_n, jn0, p2n, qn);
         };
         if constexpr (PREC == 0) {
             float a[64];
@@ -484,6 +488,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 }
             }
             request_next_geometry();
+            __builtin_amdgcn_sched_barrier(0);
             acc0 = splat16(bias[0]); acc1 = splat16(bias[1]); acc2 = splat16(bias[2]); acc3 = splat16(bias[3]);
 #pragma unroll
             for (int s_ = 0; s_ < 64; ++s_) {
@@ -514,7 +519,10 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             const float* wdb = vec + HID + 8 * hh;
 #pragma unroll
             for (int slab = 0; slab < 8; ++slab) {
-                if (slab == 4) request_next_geometry();
+                if (slab == 2) {                                   // pinned here: the results are needed after the last slab
+                    request_next_geometry();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 float us[8];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -598,6 +606,9 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             d0 = ex * ex + ey * ey + ez * ez;
         }
         pqb = pq_n;
+        p2 = p2n;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) qv[q] = qn[q];
     }
 }
 
