@@ -341,17 +341,36 @@ class EDM(torch.nn.Module):
         z = xh * fragment_mask + (draw() * linker_mask) * linker_mask
         chain = torch.zeros((keep_frames,) + z.size(), device=dev)
         coefs, (inv_alpha0, sigma0, sigma_x) = self.step_coefficients(n_samples)
+        # pocket dynamics: convert / check the masks once per chain and only enqueue kernels per step; the NaN flags of
+        # every call are OR-ed on the device and examined once at the end (a NaN never heals along the chain)
+        prep = self.dynamics.prepare(node_mask, linker_mask, edge_mask, context) if hasattr(self.dynamics, 'prepare') else None
+        seen = torch.zeros(n_samples, dtype=torch.int32, device=dev) if prep is not None else None
+        first_bad = torch.full((n_samples,), -1, dtype=torch.int32, device=dev) if prep is not None else None
+
+        def denoise(z_, t_arr_, q_):
+            if prep is None:
+                return self.dynamics.forward(xh=z_, t=t_arr_, node_mask=node_mask, linker_mask=linker_mask,
+                                             context=context, edge_mask=edge_mask)
+            out, flags = self.dynamics.launch(prep, t_arr_, z_)
+            newly = (flags != 0) & (seen == 0)
+            first_bad.masked_fill_(newly, q_)
+            seen.bitwise_or_(flags)
+            return out
+
+        t_arr = torch.empty((n_samples, 1), device=dev)
         for q, s in enumerate(reversed(range(0, self.T))):
             t_, a_, c_, sg_ = (float(v) for v in coefs[q])
-            t_arr = torch.full((n_samples, 1), t_, device=dev)
-            eps_hat = self.dynamics.forward(xh=z, t=t_arr, node_mask=node_mask, linker_mask=linker_mask,
-                                            context=context, edge_mask=edge_mask)
+            t_arr.fill_(t_)
+            eps_hat = denoise(z, t_arr, q)
             z = self._sampler_step(z, eps_hat, draw(), fragment_mask, linker_mask, _lib.DLStepCoef(t_, a_, c_, sg_))
-            chain[(s * keep_frames) // self.T] = self.unnormalize_z(z)
+            widx = (s * keep_frames) // self.T
+            if s == 0 or ((s - 1) * keep_frames) // self.T != widx:       # only the last writer of a frame survives
+                chain[widx] = self.unnormalize_z(z)
         # final decode (edm.py:210-235)
         zeros = torch.zeros(size=(n_samples, 1), device=dev)
-        eps_hat = self.dynamics.forward(t=zeros, xh=z, node_mask=node_mask, linker_mask=linker_mask,
-                                        edge_mask=edge_mask, context=context) * linker_mask
+        eps_hat = denoise(z, zeros, self.T) * linker_mask
+        if prep is not None:
+            self._raise_on_chain_flags(seen, first_bad)
         mu_x = inv_alpha0 * (z - sigma0 * eps_hat)
         xh = mu_x + sigma_x * (draw() * linker_mask)
         xh = z * fragment_mask + xh * linker_mask

@@ -330,17 +330,13 @@ class DynamicsWithPockets(Dynamics):
         super().__init__(*args, **kwargs)
         self._workspaces = {}
 
-    def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+    def prepare(self, node_mask, linker_mask, edge_mask, context):
+        """Everything of a call that does not change along a sampling chain: mask conversions, the reference's role
+        assert (egnn.py:488), the batch-index check, the workspace.  ``launch`` then only enqueues kernels."""
         assert self.graph_type in ['4A', 'FC-4A', 'FC-10A-4A']
         lib = _lib.load()
-        dev = xh.device
-        bs, n_nodes = xh.shape[0], xh.shape[1]
-        handle = self.hip_model(dev)
-        xh = self._f32(xh)
-        if not torch.is_tensor(t):
-            t = torch.tensor([float(t)])
-        t = t.to(dev, torch.float32).contiguous().view(-1)
-        t_is_scalar = int(t.numel() == 1)
+        dev = node_mask.device
+        bs, n_nodes = node_mask.shape[0], node_mask.shape[1]
         nm = node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous()
         lm = self._f32(linker_mask.reshape(bs, n_nodes))
         ctx = self._f32(context.reshape(bs, n_nodes, self.context_node_nf))
@@ -357,17 +353,32 @@ class DynamicsWithPockets(Dynamics):
         if ws is None or ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._workspaces = {key: ws}
+        return dict(bs=bs, n=n_nodes, nm=nm, lm=lm, ctx=ctx, ws=ws, need=need, handle=self.hip_model(dev), dev=dev,
+                    node_mask3=node_mask.reshape(bs, n_nodes, 1))
+
+    def launch(self, prep, t, xh):
+        """Enqueue one denoiser call for prepared masks; returns ``(eps_hat, nan_flags)`` without synchronising."""
+        lib = _lib.load()
+        dev, bs, n_nodes = prep['dev'], prep['bs'], prep['n']
+        xh = self._f32(xh)
+        if not torch.is_tensor(t):
+            t = torch.tensor([float(t)])
+        t = t.to(dev, torch.float32).contiguous().view(-1)
+        t_is_scalar = int(t.numel() == 1)
         out = torch.empty_like(xh)
         flags = torch.empty(bs, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             _lib.check(lib.dl_egnn_forward_pocket(
-                handle, bs, n_nodes, self.GRAPH_TYPES[self.graph_type], _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
-                _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(ctx), _lib.ptr(out), _lib.ptr(flags), _lib.ptr(ws), need,
-                ctypes.c_void_p(stream)), 'dl_egnn_forward_pocket')
-        self._raise_on_flags(flags)
+                prep['handle'], bs, n_nodes, self.GRAPH_TYPES[self.graph_type], _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
+                _lib.ptr(prep['nm']), _lib.ptr(prep['lm']), _lib.ptr(prep['ctx']), _lib.ptr(out), _lib.ptr(flags),
+                _lib.ptr(prep['ws']), prep['need'], ctypes.c_void_p(stream)), 'dl_egnn_forward_pocket')
         if self.centering:
-            nm3 = node_mask.reshape(bs, n_nodes, 1).to(out.dtype)
-            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], nm3)
+            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], prep['node_mask3'].to(out.dtype))
             out = torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
+        return out, flags
+
+    def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+        out, flags = self.launch(self.prepare(node_mask, linker_mask, edge_mask, context), t, xh)
+        self._raise_on_flags(flags)
         return out
