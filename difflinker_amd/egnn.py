@@ -243,7 +243,27 @@ class Dynamics(nn.Module):
         limit = _lib.load().dl_max_atoms()
         return n_nodes <= limit or int(node_mask.reshape(node_mask.shape[0], n_nodes).ne(0).sum(1).max()) <= limit
 
-    def _launch_forward(self, t, xh, node_mask, linker_mask, edge_mask, context, large=False):
+    def prepare(self, node_mask, linker_mask, edge_mask, context):
+        """Everything of a call that does not change along a sampling chain (mask conversions, the size check that picks
+        the kernel family); ``launch`` then only enqueues kernels."""
+        dev = node_mask.device
+        bs, n_nodes = node_mask.shape[0], node_mask.shape[1]
+        return dict(bs=bs, n=n_nodes, dev=dev, large=not self.fits_lds(node_mask),
+                    nm=node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous(),
+                    lm=self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None,
+                    em=edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None,
+                    ctx=self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None,
+                    node_mask3=node_mask.reshape(bs, n_nodes, 1))
+
+    def launch(self, prep, t, xh):
+        """Enqueue one denoiser call for prepared masks; returns ``(eps_hat, nan_flags)`` without synchronising."""
+        out, flags = self._launch_forward(t, xh, None, None, None, None, large=prep['large'], prep=prep)
+        if self.centering:                                     # inpainting only (egnn.py:444-445)
+            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], prep['node_mask3'].to(out.dtype))
+            out = torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
+        return out, flags
+
+    def _launch_forward(self, t, xh, node_mask, linker_mask, edge_mask, context, large=False, prep=None):
         lib = _lib.load()
         dev = xh.device
         bs, n_nodes = xh.shape[0], xh.shape[1]
@@ -254,10 +274,13 @@ class Dynamics(nn.Module):
         t = t.to(dev, torch.float32).contiguous().view(-1)
         t_is_scalar = int(t.numel() == 1)                       # egnn.py:397-399
         assert t_is_scalar or t.numel() == bs
-        nm = node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous()
-        lm = self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None
-        em = edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None
-        ctx = self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None
+        if prep is not None:
+            nm, lm, em, ctx = prep['nm'], prep['lm'], prep['em'], prep['ctx']
+        else:
+            nm = node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous()
+            lm = self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None
+            em = edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None
+            ctx = self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None
         out = torch.empty_like(xh)
         flags = torch.empty(bs, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
