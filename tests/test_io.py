@@ -90,3 +90,29 @@ def test_reference_case_study_files_parse():
     for rel in ('impdh/5ou2_fragments_input.sdf', 'jnk/3fi3_fragments.sdf', 'jnk/3fi3_linker.sdf'):
         m = io.read_molecule(os.path.join(CASES, rel))
         io.parse_molecule(m, is_geom=True)
+
+
+def test_generation_driver_helpers(tmp_path):
+    """Host-side pieces of the generation drivers (generate.py:69-99, :128-146): the three kinds of ``--linker_size``,
+    1-based anchor indices, batching, the pocket collate's fragment-only edge mask."""
+    from difflinker_amd.datasets import collate_with_fragment_without_pocket_edges
+    from difflinker_amd.generate import _anchor_flags, _batches, make_sample_fn
+    data = {'positions': torch.zeros(5, 7, 3)}
+    fixed = make_sample_fn('6', 'cpu')(data)
+    assert fixed.dtype == const.TORCH_INT and fixed.tolist() == [6] * 5
+    torch.manual_seed(0)
+    uni = make_sample_fn('3, 9', 'cpu')(data)
+    assert uni.shape == (5,) and int(uni.min()) >= 3 and int(uni.max()) <= 9
+    with pytest.raises(FileNotFoundError):
+        make_sample_fn(os.path.join(tmp_path, 'missing.ckpt'), 'cpu')
+    assert _anchor_flags(np.zeros(6), '2, 5').tolist() == [0, 1, 0, 0, 1, 0]
+    assert _anchor_flags(np.zeros(3), None).tolist() == [0, 0, 0]
+    assert [len(b) for b in _batches(list(range(10)), 4, lambda x: x)] == [4, 4, 2]
+    item = {'positions': torch.randn(5, 3), 'one_hot': torch.eye(9)[:5], 'anchors': torch.zeros(5),
+            'fragment_only_mask': torch.tensor([1., 1, 0, 0, 0]), 'pocket_mask': torch.tensor([0., 0, 1, 1, 0]),
+            'fragment_mask': torch.tensor([1., 1, 1, 1, 0]), 'linker_mask': torch.tensor([0., 0, 0, 0, 1]),
+            'num_atoms': 5, 'uuid': 0, 'name': 'm'}
+    out = collate_with_fragment_without_pocket_edges([item])
+    em = out['edge_mask'].view(5, 5)
+    assert em[:2, :2].tolist() == [[-2, -1], [-1, -2]] and float(em[2:].abs().sum() + em[:, 2:].abs().sum()) == 0.0
+    assert out['atom_mask'].view(-1).tolist() == [1, 1, 1, 1, 1] and len(out['edges'][0]) == 25
