@@ -117,8 +117,10 @@ class EDM(torch.nn.Module):
         noise_x = torch.empty((n_steps + 2, n_samples, n_nodes, self.n_dims), device=device)
         noise_h = torch.empty((n_steps + 2, n_samples, n_nodes, self.in_node_nf), device=device)
         for k in range(n_steps + 2):
-            noise_x[k] = torch.randn((n_samples, n_nodes, self.n_dims), device=device)
-            noise_h[k] = torch.randn((n_samples, n_nodes, self.in_node_nf), device=device)
+            # randn(size, out=slice) consumes the generator exactly like randn(size) does (same element count, same
+            # launch) but writes in place: no temporary, no copy kernel (tests/test_gpu_philox.py checks the equality)
+            torch.randn((n_samples, n_nodes, self.n_dims), out=noise_x[k])
+            torch.randn((n_samples, n_nodes, self.in_node_nf), out=noise_h[k])
         return noise_x, noise_h
 
     # ---- per-step scalars ---------------------------------------------------------------------------

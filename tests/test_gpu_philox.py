@@ -80,3 +80,16 @@ def test_samples_do_not_depend_on_the_batch_split():
     edm.noise_seed = 8
     other = edm.sample_chain(keep_frames=2, **args(0, 4))
     assert not torch.equal(full, other)
+
+
+def test_default_noise_bank_is_the_reference_call_sequence():
+    """The default ('torch') bank: 2(T+2) torch.randn calls in the reference's order and shapes
+    (utils.sample_gaussian_with_mask via edm.py:136,205,228 -> :328-345), drawn in place."""
+    edm, _, _ = make_edm(9, 1, T=5, seed=2)
+    B, N = 3, 17
+    torch.manual_seed(321)
+    nx, nh = edm.draw_noise_bank(B, N, dev())
+    torch.manual_seed(321)
+    for k in range(5 + 2):
+        assert torch.equal(nx[k], torch.randn((B, N, 3), device=dev()))
+        assert torch.equal(nh[k], torch.randn((B, N, 9), device=dev()))
