@@ -4,8 +4,8 @@ own Python API.  All hot-path arithmetic runs in hand-written HIP kernels for gf
 (``csrc/``, C ABI in ``include/difflinker_hip.h``); there is no CPU/PyTorch fallback.
 """
 from .egnn import Dynamics, DynamicsWithPockets          # noqa: F401
-from .edm import EDM                                     # noqa: F401
+from .edm import EDM, InpaintingEDM                      # noqa: F401
 from .lightning import DDPM                              # noqa: F401
 from .utils import FoundNaNException                     # noqa: F401
 
-__all__ = ['Dynamics', 'DynamicsWithPockets', 'EDM', 'DDPM', 'FoundNaNException']
+__all__ = ['Dynamics', 'DynamicsWithPockets', 'EDM', 'InpaintingEDM', 'DDPM', 'FoundNaNException']

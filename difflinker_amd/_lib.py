@@ -33,6 +33,13 @@ class DLSizeConfig(ctypes.Structure):
                 ('n_layers', ctypes.c_int32)]
 
 
+class DLInpaintCoef(ctypes.Structure):
+    _fields_ = [('alpha_ts', ctypes.c_float), ('c_eps', ctypes.c_float), ('sigma', ctypes.c_float),
+                ('a_q', ctypes.c_float), ('b_q', ctypes.c_float), ('decode', ctypes.c_int32),
+                ('inv_alpha0', ctypes.c_float), ('sigma0', ctypes.c_float), ('sigma_x', ctypes.c_float),
+                ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float)]
+
+
 class DLStepCoef(ctypes.Structure):
     _fields_ = [('t', ctypes.c_float), ('alpha_ts', ctypes.c_float), ('c_eps', ctypes.c_float),
                 ('sigma', ctypes.c_float)]
@@ -56,7 +63,7 @@ EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_stri
            'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
            'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
            'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
-           'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large')
+           'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large', 'dl_inpaint_step')
 
 _lib = None
 
@@ -105,6 +112,8 @@ def load():
     lib.dl_egnn_forward_fc_large.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dl_sample_chain_fc.restype = i32
     lib.dl_sample_chain_fc.argtypes = [vp, ctypes.POINTER(DLChainArgs), vp]
+    lib.dl_inpaint_step.restype = i32
+    lib.dl_inpaint_step.argtypes = [i32, i32, i32] + [vp] * 10 + [DLInpaintCoef, vp, vp]
     lib.dl_philox_fill.restype = i32
     lib.dl_philox_fill.argtypes = [ctypes.c_uint64, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dl_size_model_num_tensors.restype = i32

@@ -1369,6 +1369,106 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
 }
 
 namespace {
+// one 256-thread workgroup per molecule; D = 3 + nf <= DMAX
+__global__ void __launch_bounds__(256) inpaint_step_kernel(int N, int nf, const float* __restrict__ z_t,
+        const float* __restrict__ eps_hat, const float* __restrict__ xh_frag, const float* __restrict__ npx,
+        const float* __restrict__ nph, const float* __restrict__ nqx, const float* __restrict__ nqh,
+        const float* __restrict__ node_mask, const float* __restrict__ fragment_mask,
+        const float* __restrict__ linker_mask, dl_inpaint_coef cf, float* __restrict__ z_s) {
+    __shared__ float red[12][4];                 // per-wave partial sums
+    __shared__ float tot[12];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int D = 3 + nf;
+    const size_t base = size_t(b) * N;
+    // sums over atoms: [0..2] noise_p.x * node, [3..5] noise_q.x * qmask, [6..8] eps.x (masked by the denoiser), 9: #node, 10: #qmask
+    float part[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) part[k] = 0.0f;
+    for (int a = tid; a < N; a += 256) {
+        const float nm = node_mask[base + a];
+        const float qm = cf.decode ? nm : fragment_mask[base + a];     // q(x,h|z_0) draws its noise on the node mask
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            part[d] += npx[(base + a) * 3 + d] * nm;
+            part[3 + d] += nqx[(base + a) * 3 + d] * qm;
+            part[6 + d] += eps_hat[(base + a) * D + d];
+        }
+        part[9] += nm;
+        part[10] += qm;
+    }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        float s_ = part[k];
+        for (int off = 32; off >= 1; off >>= 1) s_ += __shfl_xor(s_, off);
+        if (lane == 0) red[k][wv] = s_;
+    }
+    __syncthreads();
+    if (tid < 11) tot[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    __syncthreads();
+    const float n_node = tot[9], n_q = tot[10];
+    // new state (before the centre-of-gravity projection), and the sum of its positions over the node mask
+    float zsum[3] = {0.0f, 0.0f, 0.0f};
+    for (int e = tid; e < N * D; e += 256) {
+        const int a = e / D, d = e - a * D;
+        const float nm = node_mask[base + a], fm = fragment_mask[base + a], lm = linker_mask[base + a];
+        const float qm = cf.decode ? nm : fm;
+        const float z = z_t[(base + a) * D + d];
+        float eps = eps_hat[(base + a) * D + d];
+        float np_, nq_;
+        if (d < 3) {
+            eps = __fsub_rn(eps, __fmul_rn(__fdiv_rn(tot[6 + d], n_node), nm));              // centred velocity
+            np_ = __fsub_rn(__fmul_rn(npx[(base + a) * 3 + d], nm), __fmul_rn(__fdiv_rn(tot[d], n_node), nm));
+            nq_ = __fsub_rn(__fmul_rn(nqx[(base + a) * 3 + d], qm), __fmul_rn(__fdiv_rn(tot[3 + d], n_q), qm));
+        } else {
+            np_ = __fmul_rn(nph[(base + a) * nf + d - 3], nm);
+            nq_ = __fmul_rn(nqh[(base + a) * nf + d - 3], qm);
+        }
+        float zl, zf;
+        if (!cf.decode) {
+            zl = __fadd_rn(__fsub_rn(__fdiv_rn(z, cf.alpha_ts), __fmul_rn(cf.c_eps, eps)), __fmul_rn(cf.sigma, np_));
+            zf = __fadd_rn(__fadd_rn(__fmul_rn(cf.a_q, z), __fmul_rn(cf.b_q, xh_frag[(base + a) * D + d])),
+                           __fmul_rn(cf.sigma, nq_));
+        } else {
+            zl = __fadd_rn(__fmul_rn(cf.inv_alpha0, __fsub_rn(z, __fmul_rn(cf.sigma0, eps))), __fmul_rn(cf.sigma_x, np_));
+            zf = __fsub_rn(__fmul_rn(cf.inv_alpha0, z), __fmul_rn(__fmul_rn(cf.sigma0, cf.inv_alpha0), nq_));
+            zl = (d < 3) ? __fmul_rn(zl, cf.norm_x) : __fadd_rn(__fmul_rn(zl, cf.norm_h), cf.bias_h);
+            zf = (d < 3) ? __fmul_rn(zf, cf.norm_x) : __fadd_rn(__fmul_rn(zf, cf.norm_h), cf.bias_h);
+        }
+        const float zn = __fadd_rn(__fmul_rn(zl, lm), __fmul_rn(zf, fm));
+        z_s[(base + a) * D + d] = zn;
+        if (d < 3) zsum[d] += zn;                   // z_s is zero outside the node mask (lm + fm = node mask)
+    }
+    if (!cf.decode) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float s_ = zsum[k];
+            for (int off = 32; off >= 1; off >>= 1) s_ += __shfl_xor(s_, off);
+            if (lane == 0) red[k][wv] = s_;
+        }
+        __syncthreads();
+        if (tid < 3) tot[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+        __syncthreads();
+        for (int e = tid; e < N * 3; e += 256) {
+            const int a = e / 3, d = e - a * 3;
+            const float nm = node_mask[base + a];
+            float* p = z_s + (base + a) * D + d;
+            *p = __fsub_rn(*p, __fmul_rn(__fdiv_rn(tot[d], n_node), nm));
+        }
+    } else {
+        __syncthreads();                             // one-hot of the features, per atom (first maximal index), * node mask
+        for (int a = tid; a < N; a += 256) {
+            float* h = z_s + (base + a) * D + 3;
+            const float nm = node_mask[base + a];
+            int best = 0;
+            float bv = h[0];
+            for (int k = 1; k < nf; ++k)
+                if (h[k] > bv) { bv = h[k]; best = k; }
+            for (int k = 0; k < nf; ++k) h[k] = (k == best) ? nm : 0.0f;
+        }
+    }
+}
+
 __global__ void philox_fill_kernel(unsigned long long seed, int mol_offset, int B, int N, int nf, int draw0, int n_draws,
                                    float* noise_x, float* noise_h) {
     const int D = 3 + nf;
@@ -1385,6 +1485,18 @@ __global__ void philox_fill_kernel(unsigned long long seed, int mol_offset, int 
     }
 }
 }  // namespace
+
+int32_t dl_inpaint_step(int32_t B, int32_t N, int32_t nf, const float* z_t, const float* eps_hat, const float* xh_frag,
+                        const float* noise_px, const float* noise_ph, const float* noise_qx, const float* noise_qh,
+                        const float* node_mask, const float* fragment_mask, const float* linker_mask,
+                        dl_inpaint_coef coef, float* z_s, void* stream) {
+    if (!z_t || !eps_hat || !xh_frag || !noise_px || !noise_ph || !noise_qx || !noise_qh || !node_mask ||
+        !fragment_mask || !linker_mask || !z_s || B < 0 || N < 1 || nf < 1 || 3 + nf > DMAX) return DL_ERR_BAD_ARG;
+    if (B == 0) return DL_OK;
+    hipLaunchKernelGGL(inpaint_step_kernel, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), N, nf, z_t, eps_hat,
+                       xh_frag, noise_px, noise_ph, noise_qx, noise_qh, node_mask, fragment_mask, linker_mask, coef, z_s);
+    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
 
 int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, int32_t B, int32_t N, int32_t nf, int32_t draw0,
                        int32_t n_draws, float* noise_x, float* noise_h, void* stream) {

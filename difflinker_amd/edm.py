@@ -380,3 +380,117 @@ class EDM(torch.nn.Module):
         h = F.one_hot(torch.argmax(h, dim=2), self.in_node_nf) * node_mask
         chain[0] = torch.cat([x, h], dim=2)
         return chain
+
+
+class InpaintingEDM(EDM):
+    """``InpaintingEDM`` (edm.py:466-727), sampling side: every atom is denoised (``linker_mask=None``, centred dynamics),
+    the linker atoms keep the ``p(z_s | z_t)`` sample, the fragment atoms are re-drawn from ``q(z_s | z_t, x)``, and the
+    centre of gravity is projected out after every step.  One HIP denoiser call + one fused HIP tail
+    (``dl_inpaint_step``) per step; no released configuration uses it."""
+
+    def inpaint_coefficients(self, batch_size=1):
+        """Per-step scalars in execution order: ``(t, alpha_ts, c_eps, sigma, a_q, b_q)`` (edm.py:616-672), evaluated on
+        ``[batch_size, 1]`` CPU tensors like ``EDM.step_coefficients``."""
+        if self.coef_batch is not None:
+            batch_size = self.coef_batch
+        gamma = self.gamma.gamma.detach().to('cpu', torch.float32)
+        timesteps = self.gamma.timesteps
+        lookup = lambda tt: gamma[torch.round(tt * timesteps).long()]       # noqa: E731
+        rows = []
+        for s_int in reversed(range(0, self.T)):
+            s = torch.full((batch_size, 1), fill_value=s_int)
+            t = (s + 1) / self.T
+            s = s / self.T
+            gamma_s, gamma_t = lookup(s), lookup(t)
+            sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(gamma_t, gamma_s, gamma_t)
+            sigma_s = torch.sqrt(torch.sigmoid(gamma_s))
+            sigma_t = torch.sqrt(torch.sigmoid(gamma_t))
+            alpha_s = torch.sqrt(torch.sigmoid(-gamma_s))
+            c_eps = sigma2_ts / alpha_ts / sigma_t
+            sigma = sigma_ts * sigma_s / sigma_t
+            a_q = alpha_ts * (sigma_s ** 2) / (sigma_t ** 2)
+            b_q = alpha_s * sigma2_ts / (sigma_t ** 2)
+            rows.append([float(v[0, 0]) for v in (t, alpha_ts, c_eps, sigma, a_q, b_q)])
+        return rows
+
+    def draw_inpainting_noise_bank(self, n_samples, n_nodes, device):
+        """The ``torch.randn`` calls of one chain in the reference's order: initial z, then (p, q) per step, then the p
+        and q draws of the decode; each an x-part ``[B,N,3]`` and an h-part ``[B,N,nf]`` (utils.py:158-168,189-192)."""
+        n = 1 + 2 * self.T + 2
+        noise_x = torch.empty((n, n_samples, n_nodes, self.n_dims), device=device)
+        noise_h = torch.empty((n, n_samples, n_nodes, self.in_node_nf), device=device)
+        for k in range(n):
+            torch.randn((n_samples, n_nodes, self.n_dims), out=noise_x[k])
+            torch.randn((n_samples, n_nodes, self.in_node_nf), out=noise_h[k])
+        return noise_x, noise_h
+
+    @torch.no_grad()
+    def sample_chain(self, x, h, node_mask, edge_mask, fragment_mask, linker_mask, context, keep_frames=None,
+                     noise_bank=None):
+        dev = x.device
+        if dev.type != 'cuda':
+            raise RuntimeError('difflinker_amd.InpaintingEDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
+        if not getattr(self.dynamics, 'centering', False):
+            raise ValueError('InpaintingEDM needs a centred denoiser (Dynamics(centering=True), lightning.py:99)')
+        lib = _lib.load()
+        bs, n = x.size(0), x.size(1)
+        nf, T = self.in_node_nf, self.T
+        keep_frames = T if keep_frames is None else keep_frames
+        assert keep_frames <= T
+        if noise_bank is None:
+            noise_x, noise_h = self.draw_inpainting_noise_bank(bs, n, dev)
+        else:
+            noise_x, noise_h = (t_.to(dev, torch.float32).contiguous() for t_ in noise_bank)
+            assert noise_x.shape[0] == 1 + 2 * T + 2
+        f32 = lambda t_, shape: t_.reshape(shape).to(torch.float32).contiguous()      # noqa: E731
+        nm, fm, lm = f32(node_mask, (bs, n)), f32(fragment_mask, (bs, n)), f32(linker_mask, (bs, n))
+        xn, hn = self.normalize(x, h)
+        xh = torch.cat([xn, hn], dim=2).float()
+        xh_frag = (xh * fm.unsqueeze(-1)).contiguous()
+        # initial z: centre-of-gravity-free position noise + feature noise on the node mask (edm.py:559, :715-727)
+        nm3 = nm.unsqueeze(-1)
+        zx = noise_x[0] * nm3
+        zx = zx - (zx.sum(1, keepdim=True) / nm3.sum(1, keepdim=True)) * nm3
+        z = torch.cat([zx, noise_h[0] * nm3], dim=2).contiguous()
+        chain = torch.zeros((keep_frames,) + z.size(), device=dev)
+        rows = self.inpaint_coefficients(bs)
+        _, (inv_alpha0, sigma0, sigma_x) = self.step_coefficients(bs)
+        prep = self.dynamics.prepare(node_mask, None, edge_mask, context)
+        seen = torch.zeros(bs, dtype=torch.int32, device=dev)
+        first_bad = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+        t_arr = torch.empty((bs, 1), device=dev)
+        norm = dict(norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]))
+
+        def tail(z_, eps_, k_p, k_q, coef):
+            out = torch.empty_like(z_)
+            with torch.cuda.device(dev):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                _lib.check(lib.dl_inpaint_step(bs, n, nf, _lib.ptr(z_), _lib.ptr(eps_), _lib.ptr(xh_frag),
+                                               _lib.ptr(noise_x[k_p]), _lib.ptr(noise_h[k_p]), _lib.ptr(noise_x[k_q]),
+                                               _lib.ptr(noise_h[k_q]), _lib.ptr(nm), _lib.ptr(fm), _lib.ptr(lm), coef,
+                                               _lib.ptr(out), ctypes.c_void_p(stream)), 'dl_inpaint_step')
+            return out
+
+        def denoise(z_, q_):
+            eps_, flags = self.dynamics._launch_forward(t_arr, z_, None, None, None, None, large=prep['large'], prep=prep)
+            first_bad.masked_fill_((flags != 0) & (seen == 0), q_)
+            seen.bitwise_or_(flags)
+            return eps_
+
+        for q, s in enumerate(reversed(range(0, T))):
+            t_, a_, c_, sg_, aq_, bq_ = rows[q]
+            t_arr.fill_(t_)
+            eps_hat = denoise(z, q)
+            coef = _lib.DLInpaintCoef(alpha_ts=a_, c_eps=c_, sigma=sg_, a_q=aq_, b_q=bq_, decode=0, inv_alpha0=0.0,
+                                      sigma0=0.0, sigma_x=0.0, **norm)
+            z = tail(z, eps_hat, 1 + 2 * q, 2 + 2 * q, coef)
+            widx = (s * keep_frames) // T
+            if s == 0 or ((s - 1) * keep_frames) // T != widx:
+                chain[widx] = self.unnormalize_z(z)
+        t_arr.fill_(0.0)
+        eps_hat = denoise(z, T)
+        self._raise_on_chain_flags(seen, first_bad)
+        coef = _lib.DLInpaintCoef(alpha_ts=1.0, c_eps=0.0, sigma=0.0, a_q=0.0, b_q=0.0, decode=1, inv_alpha0=inv_alpha0,
+                                  sigma0=sigma0, sigma_x=sigma_x, **norm)
+        chain[0] = tail(z, eps_hat, 1 + 2 * T, 2 + 2 * T, coef)
+        return chain

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import utils
 from .datasets import create_templates_for_linker_generation
-from .edm import EDM
+from .edm import EDM, InpaintingEDM
 from .egnn import Dynamics, DynamicsWithPockets
 
 try:  # pragma: no cover
@@ -75,9 +75,8 @@ class DDPM(_Base):
             graph_type = '4A' if self.pockets else 'FC'
         if type(activation) is str:
             activation = get_activation(activation)
-        if inpainting:
-            raise NotImplementedError('inpainting=True (InpaintingEDM, edm.py:466-730) is not part of the '
-                                      'sampling hot path of the released configs')
+        if inpainting and self.pockets:
+            raise NotImplementedError('inpainting with pocket-conditioned dynamics')
 
         dynamics_class = DynamicsWithPockets if self.pockets else Dynamics
         dynamics = dynamics_class(
@@ -87,7 +86,8 @@ class DDPM(_Base):
             normalization_factor=normalization_factor, aggregation_method=aggregation_method, model=model,
             normalization=normalization, centering=inpainting, graph_type=graph_type,
         )
-        self.edm = EDM(
+        edm_class = InpaintingEDM if inpainting else EDM           # lightning.py:102
+        self.edm = edm_class(
             dynamics=dynamics, in_node_nf=in_node_nf, n_dims=n_dims, timesteps=diffusion_steps,
             noise_schedule=diffusion_noise_schedule, noise_precision=diffusion_noise_precision,
             loss_type=diffusion_loss_type, norm_values=normalize_factors,
@@ -149,7 +149,8 @@ class DDPM(_Base):
             linker_sizes = data['linker_mask'].sum(1).view(-1).int()
         else:
             linker_sizes = sample_fn(data)
-        template_data = create_templates_for_linker_generation(data, linker_sizes)
+        # inpainting re-draws the fragments around the given atoms: no templates (lightning.py:411-414)
+        template_data = data if self.inpainting else create_templates_for_linker_generation(data, linker_sizes)
 
         x = template_data['positions']
         node_mask = template_data['atom_mask']
@@ -171,7 +172,9 @@ class DDPM(_Base):
             else:
                 context = torch.cat([fragment_only_mask, pocket_only_mask], dim=-1)
 
-        if self.pockets and self.center_of_mass == 'fragments':
+        if self.inpainting:
+            center_of_mass_mask = node_mask
+        elif self.pockets and self.center_of_mass == 'fragments':
             center_of_mass_mask = template_data['fragment_only_mask']
         elif self.center_of_mass == 'fragments':
             center_of_mass_mask = fragment_mask

@@ -186,6 +186,25 @@ typedef struct dl_chain_args {
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
 
+/* One step of InpaintingEDM.sample_chain after the denoiser call (src/edm.py:568-596), or its final decode
+ * (:599-610, :674-713), for one batch: the linker atoms take the p(z_s|z_t) sample, the fragment atoms are re-drawn from
+ * q(z_s|z_t,x), the position noise is centre-of-gravity free (utils.py:158-168), the denoiser's velocity is centred
+ * (egnn.py:444-445) and the centre of gravity of z_s is projected out. */
+typedef struct dl_inpaint_coef {
+    float alpha_ts, c_eps, sigma;           /* p: mu = z/alpha_ts - c_eps*eps_hat;  sigma of both draws   */
+    float a_q, b_q;                         /* q: mu = a_q*z + b_q*(xh*fragment_mask)                     */
+    int32_t decode;                         /* 0: reverse step, 1: final decode                           */
+    float inv_alpha0, sigma0, sigma_x;      /* decode scalars                                             */
+    float norm_x, norm_h, bias_h;           /* decode: un-normalisation, then one-hot of the features     */
+} dl_inpaint_coef;
+/*   z_t, eps_hat, xh_frag, z_s  device f32 [B,N,3+nf]   (eps_hat: raw denoiser output, centred here)
+ *   noise_p*, noise_q*          device f32 [B,N,3] / [B,N,nf]: the four torch.randn draws of the step, unmasked
+ *   node_mask, fragment_mask, linker_mask  device f32 [B,N] */
+int32_t dl_inpaint_step(int32_t B, int32_t N, int32_t nf, const float* z_t, const float* eps_hat, const float* xh_frag,
+                        const float* noise_px, const float* noise_ph, const float* noise_qx, const float* noise_qh,
+                        const float* node_mask, const float* fragment_mask, const float* linker_mask,
+                        dl_inpaint_coef coef, float* z_s, void* stream);
+
 /* The in-kernel noise stream as a bank (for host-driven loops and tests): Philox4x32-10, key = seed, counter =
  * (mol_offset + b, atom position n, draw0 + k, component / 4), four outputs -> four standard normals by Box-Muller;
  * component d < 3 is noise_x[k][b][n][d], d >= 3 is noise_h[k][b][n][d-3].  Independent of the batch split. */

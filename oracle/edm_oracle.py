@@ -146,6 +146,81 @@ class EDMOracle:
         return chain
 
 
+def remove_mean_with_mask(x, node_mask):
+    """utils.py:56-63 (without its masking assert)."""
+    n = node_mask.sum(1, keepdims=True)
+    return x - (torch.sum(x, dim=1, keepdim=True) / n) * node_mask
+
+
+class InpaintingEDMOracle(EDMOracle):
+    """Functional twin of ``InpaintingEDM`` restricted to sampling (edm.py:549-727): every atom is denoised
+    (``linker_mask=None``, centred dynamics), the fragment atoms are re-drawn from ``q(z_s | z_t, x)`` each step and the
+    centre of gravity is projected out after every step; the position noise is centre-of-gravity free."""
+
+    def combined_noise(self, noise_fn, n_samples, n_nodes, mask):  # edm.py:715-727
+        z_x = remove_mean_with_mask(noise_fn((n_samples, n_nodes, self.n_dims), mask), mask)   # utils.py:158-168
+        z_h = noise_fn((n_samples, n_nodes, self.in_node_nf), mask)
+        return torch.cat([z_x, z_h], dim=2)
+
+    def p_zs(self, s, t, z_t, node_mask, edge_mask, context, noise_fn):
+        """edm.py:616-650."""
+        g_s, g_t = self.gamma(s), self.gamma(t)
+        sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(g_t, g_s, z_t)
+        sigma_s, sigma_t = self.sigma(g_s, z_t), self.sigma(g_t, z_t)
+        eps_hat = self.denoise(t, z_t, node_mask, None, edge_mask, context)
+        mu = z_t / alpha_ts - (sigma2_ts / alpha_ts / sigma_t) * eps_hat
+        sigma = sigma_ts * sigma_s / sigma_t
+        return mu + sigma * self.combined_noise(noise_fn, mu.size(0), mu.size(1), node_mask)
+
+    def q_zs(self, s, t, z_t, x, node_mask, noise_fn):
+        """edm.py:652-672."""
+        g_s, g_t = self.gamma(s), self.gamma(t)
+        sigma2_ts, sigma_ts, alpha_ts = self.sigma_and_alpha_t_given_s(g_t, g_s, z_t)
+        sigma_s, sigma_t = self.sigma(g_s, z_t), self.sigma(g_t, z_t)
+        alpha_s = self.alpha(g_s, x)
+        mu = alpha_ts * (sigma_s ** 2) / (sigma_t ** 2) * z_t + alpha_s * sigma2_ts / (sigma_t ** 2) * x
+        sigma = sigma_ts * sigma_s / sigma_t
+        return mu + sigma * self.combined_noise(noise_fn, mu.size(0), mu.size(1), node_mask)
+
+    @torch.no_grad()
+    def sample_chain(self, x, h, node_mask, edge_mask, fragment_mask, linker_mask, context, noise_fn, keep_frames=None):
+        """``InpaintingEDM.sample_chain`` edm.py:549-614."""
+        n_samples, n_nodes = x.size(0), x.size(1)
+        x, h = self.normalize(x, h)
+        xh = torch.cat([x, h], dim=2)
+        z = self.combined_noise(noise_fn, n_samples, n_nodes, node_mask)
+        keep_frames = self.T if keep_frames is None else keep_frames
+        assert keep_frames <= self.T
+        chain = torch.zeros((keep_frames,) + z.size(), dtype=z.dtype, device=z.device)
+        for s in reversed(range(0, self.T)):
+            s_arr = torch.full((n_samples, 1), fill_value=s, device=z.device)
+            t_arr = ((s_arr + 1) / self.T).to(z.dtype)
+            s_arr = (s_arr / self.T).to(z.dtype)
+            z_l = self.p_zs(s_arr, t_arr, z, node_mask, edge_mask, context, noise_fn)
+            z_f = self.q_zs(s_arr, t_arr, z, xh * fragment_mask, fragment_mask, noise_fn)
+            z = z_l * linker_mask + z_f * fragment_mask
+            z = torch.cat([remove_mean_with_mask(z[:, :, :self.n_dims], node_mask), z[:, :, self.n_dims:]], dim=2)
+            chain[(s * keep_frames) // self.T] = self.unnormalize_z(z)
+        # p(x, h | z_0) for the linker, q(x, h | z_0) for the fragments (edm.py:674-713)
+        zeros = torch.zeros((n_samples, 1), dtype=z.dtype, device=z.device)
+        g_0 = self.gamma(zeros)
+        sigma_x = torch.exp(-(-0.5 * g_0)).unsqueeze(1)
+        eps_hat = self.denoise(zeros, z, node_mask, None, edge_mask, context)
+        mu_x = 1. / self.alpha(g_0, eps_hat) * (z - self.sigma(g_0, eps_hat) * eps_hat)
+        xh_l = mu_x + sigma_x * self.combined_noise(noise_fn, n_samples, n_nodes, node_mask)
+        x_l, h_l = self.unnormalize(xh_l[:, :, :self.n_dims], xh_l[:, :, self.n_dims:])
+        h_l = F.one_hot(torch.argmax(h_l, dim=2), self.in_node_nf) * node_mask
+        alpha_0, sigma_0 = self.alpha(g_0, z), self.sigma(g_0, z)
+        eps = self.combined_noise(noise_fn, n_samples, n_nodes, node_mask)
+        xh_f = (1 / alpha_0) * z - (sigma_0 / alpha_0) * eps
+        x_f, h_f = self.unnormalize(xh_f[:, :, :self.n_dims], xh_f[:, :, self.n_dims:])
+        h_f = F.one_hot(torch.argmax(h_f, dim=2), self.in_node_nf) * node_mask
+        out_l = torch.cat([x_l, h_l.to(x_l.dtype)], dim=2)
+        out_f = torch.cat([x_f, h_f.to(x_f.dtype)], dim=2)
+        chain[0] = out_l * linker_mask + out_f * fragment_mask
+        return chain
+
+
 class NoiseBank:
     """Replayable noise: ``2*(T+2)`` draws in reference order (x-part then h-part).
 

@@ -166,6 +166,54 @@ def collate_masks():
 
 
 @torch.no_grad()
+def inpainting_chain():
+    """InpaintingEDM.sample_chain (src/edm.py:549-727) on a centred Dynamics, T=8 on the 500-entry gamma table, with the
+    ``torch.randn`` calls of its noise helpers (utils.py:158-168,189-192) served from a bank."""
+    from src.edm import InpaintingEDM
+    nf, ctx, L, T, keep = 8, 1, 2, 8, 3
+    data = ragged_fc_batch([12, 7, 10], [4, 2, 3], nf, seed=31)
+    inp = synthetic.sampler_inputs(data)
+    B, N = inp['x'].shape[:2]
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, device='cpu', n_layers=L,
+                   attention=False, tanh=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False,
+                   normalization_factor=100, aggregation_method='sum', model='egnn_dynamics',
+                   normalization='batch_norm', centering=True, graph_type='FC')
+    dyn.load_state_dict(seeded_state_dict(nf + ctx + 1, 128, L, 22, coord_gain=0.02), strict=True)
+    dyn.eval()
+    edm = InpaintingEDM(dynamics=dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+                        noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
+    edm.T = T
+    g = torch.Generator().manual_seed(32)
+    draws = []
+    for _ in range(1 + 2 * T + 2):                        # initial z, (p, q) per step, p and q of the decode
+        draws.append(torch.randn((B, N, 3), generator=g))
+        draws.append(torch.randn((B, N, nf), generator=g))
+    pos = [0]
+    real_randn = torch.randn
+
+    def banked(size, device=None, **kw):
+        d = draws[pos[0]]
+        assert tuple(d.shape) == tuple(size)
+        pos[0] += 1
+        return d.clone()
+
+    nm = inp['node_mask'].float()
+    x = ref_utils.remove_mean_with_mask(inp['x'] * nm, nm)  # lightning.py:441-446: inpainting centres on all atoms
+    torch.randn = banked
+    try:
+        chain = edm.sample_chain(x=x, h=inp['h'], node_mask=nm, edge_mask=inp['edge_mask'],
+                                 fragment_mask=inp['fragment_mask'], linker_mask=inp['linker_mask'],
+                                 context=inp['context'], keep_frames=keep)
+    finally:
+        torch.randn = real_randn
+    assert pos[0] == len(draws)
+    save('inpainting_chain', nf=nf, ctx=ctx, n_layers=L, T=T, keep_frames=keep, weight_seed=22, coord_gain=0.02,
+         x=x, h=inp['h'], node_mask=inp['node_mask'], fragment_mask=inp['fragment_mask'],
+         linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'], context=inp['context'],
+         noise_x=torch.stack(draws[0::2]), noise_h=torch.stack(draws[1::2]), chain=chain)
+
+
+@torch.no_grad()
 def size_gnn():
     """Linker-size predictor: the unmodified ``SizeGNN`` (src/linker_size.py:45-91) driven exactly as
     ``SizeClassifier.forward`` does at inference (src/linker_size_lightning.py:83-110; that module itself needs
@@ -215,3 +263,4 @@ if __name__ == '__main__':
     fc_chain()
     pocket_forward()
     size_gnn()
+    inpainting_chain()

@@ -558,3 +558,47 @@ def test_pocket_chain_vs_oracle():
     got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
                            g['context'], keep_frames=2, noise_bank=bank.stacked()).cpu()
     check_chain('pocket chain T=6', got, want, inp)
+
+
+# ---------------------------------------------------------------------------------------------------
+# InpaintingEDM (edm.py:549-727): centred dynamics, fragments re-drawn from q, centre of gravity projected out
+def test_inpainting_chain_vs_reference_golden_and_oracle(golden_dir):
+    from difflinker_amd import InpaintingEDM, Dynamics
+    g = load_golden(golden_dir, 'inpainting_chain')
+    nf, ctx, L, T, keep = g['nf'], g['ctx'], g['n_layers'], g['T'], g['keep_frames']
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, n_layers=L, norm_constant=1e-6,
+                   normalization='batch_norm', centering=True)
+    dyn.load_state_dict(seeded_state_dict(nf + ctx + 1, 128, L, g['weight_seed'], coord_gain=g['coord_gain']), strict=True)
+    edm = InpaintingEDM(dyn.to(dev()), in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+                        noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10]).to(dev())
+    edm.T = T
+    d = dev()
+    got = edm.sample_chain(g['x'].to(d), g['h'].to(d), g['node_mask'].to(d), g['edge_mask'].to(d),
+                           g['fragment_mask'].to(d), g['linker_mask'].to(d), g['context'].to(d), keep_frames=keep,
+                           noise_bank=(g['noise_x'], g['noise_h'])).cpu()
+    want = g['chain']
+    nm = g['node_mask'].float()
+    ex = rel_l2(got[..., :3], want[..., :3])
+    mism = int((got[0, :, :, 3:] != want[0, :, :, 3:]).any(-1).sum())
+    print(f'[inpainting chain T={T}] x rel-L2 {ex:.3e}, one-hot mismatches {mism}, frames rel-L2 {rel_l2(got[1:], want[1:]):.3e}')
+    assert got.shape == want.shape and ex <= CHAIN_TOL and rel_l2(got[1:], want[1:]) <= CHAIN_TOL and mism == 0
+    assert float((got * (1 - nm)).abs().max()) == 0.0
+    assert float((got[1:, :, :, :3] * nm).sum(2).abs().max()) <= 1e-4, 'centre of gravity projected out every step'
+    # DDPM(inpainting=True) builds this sampler on a centred denoiser (lightning.py:99-102)
+    from difflinker_amd import DDPM
+    hp = dict(in_node_nf=8, n_dims=3, context_node_nf=1, hidden_nf=128, activation='silu', tanh=False, n_layers=1,
+              attention=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+              aggregation_method='sum', diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+              diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4, 10],
+              include_charges=False, model='egnn_dynamics', data_path='d', train_data_prefix='zinc_final_train',
+              val_data_prefix='zinc_final_val', batch_size=8, lr=2e-4, torch_device='cuda:0', test_epochs=20,
+              n_stability_samples=10, normalization='batch_norm', anchors_context=False, inpainting=True)
+    m = DDPM(**hp).to(d).eval()
+    assert isinstance(m.edm, InpaintingEDM) and m.edm.dynamics.centering
+    m.edm.T = 4
+    from difflinker_amd import synthetic
+    data, _ = synthetic.make_batch('C1', seed=2, batch=3, device=d)
+    torch.manual_seed(5)
+    chain, node_mask = m.sample_chain(data, keep_frames=1)
+    assert chain.shape[1:3] == data['positions'].shape[:2] and torch.isfinite(chain).all()
+    assert torch.equal(chain[0][..., 3:].sum(-1), node_mask.squeeze(-1).float())
