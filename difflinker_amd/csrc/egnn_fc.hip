@@ -55,12 +55,13 @@ static_assert(THREADS == 512 || THREADS == 768, "8 grid waves + 0 or 4 helper wa
 // pair-tile shares of the waves sharing a SIMD (w, w+4[, w+8]), oldest first: the older wave wins the issue
 // arbitration and gets through more tiles per unit time; static, contiguous ranges (deterministic reduction).
 // Measured (n = 50, ticks per forward; before / after the spill clean-up): 8:8 4.13 M, 9:7 4.01 M, 10:6 3.94 / 3.38 M,
-// 21:11 3.34 M, 11:5 3.41 M, 12:4 4.11 M, one wave only 4.97 M.
+// 21:11 3.34 M, 11:5 3.41 M, 12:4 4.11 M, one wave only 4.97 M; with the iterative-ILP scheduler (build flag): 21:11 3.31 M,
+// 22:10 3.39 M, 23:9 3.26 M.
 #ifndef DL_SHARE0
-#define DL_SHARE0 (DL_THREADS == 512 ? 21 : 6)
+#define DL_SHARE0 (DL_THREADS == 512 ? 23 : 6)
 #endif
 #ifndef DL_SHARE1
-#define DL_SHARE1 (DL_THREADS == 512 ? 11 : 5)
+#define DL_SHARE1 (DL_THREADS == 512 ? 9 : 5)
 #endif
 #ifndef DL_SHARE2
 #define DL_SHARE2 (DL_THREADS == 512 ? 0 : 5)

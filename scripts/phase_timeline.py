@@ -25,7 +25,8 @@ if 'DIFFLINKER_HIP_LIB' not in os.environ:
     if not os.path.exists(prof_lib) or any(os.path.getmtime(src) > os.path.getmtime(prof_lib) for src in entry.HIP_SOURCES):
         os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
         subprocess.run([entry.HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC', '-Wno-unused-value',
-                        '-DDL_PROFILE', '-I', os.path.join(ROOT, 'include')] + entry.HIP_SOURCES + ['-o', prof_lib], check=True)
+                        '-DDL_PROFILE', '-I', os.path.join(ROOT, 'include')] + entry.EXTRA_FLAGS['egnn_fc.hip'] +
+                       entry.HIP_SOURCES + ['-o', prof_lib], check=True)
     os.environ['DIFFLINKER_HIP_LIB'] = prof_lib
 entry.build()
 from difflinker_amd import Dynamics, synthetic, _lib
