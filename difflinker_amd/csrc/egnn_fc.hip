@@ -37,36 +37,13 @@ namespace {
 
 constexpr int LDH = 132;            // LDS row stride of [n,128] fp32 tiles: 528 B = 33 x 16 B (conflict-free b128)
 constexpr int NMAX = 55;            // real atoms per molecule that fit the LDS-resident layout
-// Workgroup = GWAVES "grid" waves (w < 8: own the 2 x 4 grid of 32x32 output tiles of every per-node GEMM and the
-// matching register tile of h) + optional helper waves (w >= 8) that only take part in the pair passes, where a
-// third wave per SIMD hides the LDS / transcendental / MFMA latencies the first two leave exposed.
-#ifndef DL_THREADS
-#define DL_THREADS 512
-#endif
-constexpr int THREADS = DL_THREADS;
+// Workgroup = 8 waves = two per SIMD: they own the 2 x 4 grid of 32x32 output tiles of every per-node GEMM (and the
+// matching register tile of h) and 32 pair slots each in the pair passes.  (A third wave per SIMD - a 768-thread build
+// with helper waves - measured equal in round 1 and does not fit the register budget of the pair loop: removed.)
+constexpr int THREADS = 512;
 constexpr int NWAVES = THREADS / 64;
 constexpr int GWAVES = 8;
 constexpr int GTHREADS = 64 * GWAVES;
-// helper-wave builds run three waves per SIMD = 168 VGPRs per lane: the node phases then hold ONE weight fragment (64
-// VGPRs) at a time and request it at the point of use (no cross-phase prefetch), which keeps them free of spills
-constexpr bool LEAN = NWAVES > GWAVES;
-__device__ __forceinline__ bool grid_wave(int w) { return NWAVES == GWAVES || w < GWAVES; }
-static_assert(THREADS == 512 || THREADS == 768, "8 grid waves + 0 or 4 helper waves");
-// pair-tile shares of the waves sharing a SIMD (w, w+4[, w+8]), oldest first: the older wave wins the issue
-// arbitration and gets through more tiles per unit time; static, contiguous ranges (deterministic reduction).
-// Measured (n = 50, ticks per forward; before / after the spill clean-up): 8:8 4.13 M, 9:7 4.01 M, 10:6 3.94 / 3.38 M,
-// 21:11 3.34 M, 11:5 3.41 M, 12:4 4.11 M, one wave only 4.97 M; with the iterative-ILP scheduler (build flag): 21:11 3.31 M,
-// 22:10 3.39 M, 23:9 3.26 M.
-#ifndef DL_SHARE0
-#define DL_SHARE0 (DL_THREADS == 512 ? 23 : 6)
-#endif
-#ifndef DL_SHARE1
-#define DL_SHARE1 (DL_THREADS == 512 ? 9 : 5)
-#endif
-#ifndef DL_SHARE2
-#define DL_SHARE2 (DL_THREADS == 512 ? 0 : 5)
-#endif
-
 // ---- LDS layout (floats) ---------------------------------------------------------------------------
 constexpr int L_A = 0;                                // P  / h row-major / eps (aliased at the end)
 constexpr int L_B = L_A + NMAX * LDH;                 // Q  / node-MLP hidden
@@ -84,8 +61,7 @@ constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
 constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
-constexpr int L_MSCR = L_DUMMY + LDH;                 // per-wave edge-mask bytes of the current tile [NWAVES][32] int8
-constexpr int L_TOTAL = L_MSCR + 8 * NWAVES;
+constexpr int L_TOTAL = L_DUMMY + LDH;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -96,7 +72,6 @@ struct Lds {
     int *idx, *misc;
     unsigned* fmax;
     float* dummy;
-    signed char* mscr;
 };
 
 __device__ __forceinline__ Lds lds_view(float* base) {
@@ -107,7 +82,6 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
     v.fmax = reinterpret_cast<unsigned*>(base + L_FMAX);
     v.dummy = base + L_DUMMY;
-    v.mscr = reinterpret_cast<signed char*>(base + L_MSCR);
     return v;
 }
 
@@ -122,7 +96,7 @@ struct Prof {
 };
 __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
 #ifdef DL_PROFILE
-    if (pf.buf != nullptr && grid_wave(w)) {
+    if (pf.buf != nullptr) {
         if (lane == 0 && pf.n < PROF_MAX_EVENTS) {
             unsigned long long* e = pf.buf + (size_t(w) * PROF_MAX_EVENTS + pf.n) * 2;
             e[0] = (unsigned long long)tag;
@@ -260,7 +234,7 @@ __device__ __forceinline__ void load_next(PreW& pw, const NextPass& nx, int w, i
 }
 __device__ __forceinline__ void stage_next(const Lds& v, const NextPass& nx, int w, int tid) {
     if (nx.base == nullptr) return;
-    stage_dma(v, nx.base + (nx.equiv ? E_W6 : G_W2), nx.base + (nx.equiv ? E_VEC : G_VEC) + HID, w, tid);
+    stage_dma(v, nx.base + (nx.equiv ? E_W6T : G_W2T), nx.base + (nx.equiv ? E_VEC : G_VEC) + HID, w, tid);
 }
 
 // store one accumulator element of tile row `row` to a [n][LDH] buffer; rows >= n_b go to the sink row
@@ -294,282 +268,324 @@ __device__ __forceinline__ float node_pre(const Lds& v, int nb, int w, int lane,
     return vmax;
 }
 
-// One pass over all n_b^2 ordered pairs of the molecule.
-//   EQUIV = false: agg[i][f] += m_ij * u2_ij[f]           (GCL message sum, into v.C)
-//   EQUIV = true : aggx[i]   += cdiff_ij * (w7'.u2_ij) * m_ij (coordinate head, into v.aggx)
-// Pairs are flattened p = i*n_b + j and cut into tiles of 32; wave w takes the contiguous tile range
-// [w*ntiles/8, (w+1)*ntiles/8).  The sum over j is DETERMINISTIC: every aggregate row i is written
-// by exactly one wave — the one for which atom i is not the first atom of its range; a wave's
-// contribution to its first atom (which the previous wave may share) is kept in registers
-// (`spill`) and folded in afterwards in wave order (spill_reduce_*).  spill_row = -1: nothing.
-struct Spill {
-    int row;
-    float v[4];
+// f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
+constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, FM_X02 = 6;
+
+// One pass over all n_b^2 ordered pairs of the molecule, "receiver-stationary":
+//   * the 256 lane pairs (c, c+32) of the 8 waves are SLOTS; atom i owns g = min(256 / n_b, n_b) consecutive slots and
+//     slot (i, chunk) walks the senders j = chunk*q + t, t = 0 .. q-1, q = ceil(n_b / g): one MFMA column per slot, the
+//     receiving atom of a lane never changes, so the sum over j is a plain in-register accumulation (no cross-lane
+//     reduction, no LDS traffic inside the loop) and its order is fixed (t ascending, then chunks ascending in
+//     pair_reduce): DETERMINISTIC.
+//   * both edge layers are computed TRANSPOSED, features x pairs: D1[f][pair] = (P_i + Q_j)[f] + wr[f] r + wd[f] d0 comes
+//     out of the matrix pipe in the accumulator layout (lane = pair, registers = 16 features per 32-feature tile), which IS
+//     the B-operand layout of the next MFMA (lane = column, registers = k) once the k-slots of W2' are permuted to match
+//     (host: pack_lds_image*_t): SiLU(D1) feeds D2 = W2' * SiLU(D1) without any data movement, and D2 again has lane = pair,
+//     so the message lands in the receiver's accumulators.  The rank-2 geometric term runs on the matrix pipe too
+//     (f16x3: one split-fp16 MFMA per feature tile; fp32: one v_mfma_f32_32x32x2_f32).
+//   EQUIV = false: agg[i][f]  = sum_j m_ij * u2_ij[f]              (GCL message sum)      -> partial rows
+//   EQUIV = true : aggx[i]    = sum_j cdiff_ij * (w7'.u2_ij) * m_ij (coordinate head)      -> partial triples
+// The partials of the g slots of an atom are written to LDS (over P, Q, H and W2', dead by then) after the barrier that
+// ends the loop; pair_reduce_* adds them in chunk order.
+#ifndef DL_DBG_NSLOT
+#define DL_DBG_NSLOT (32 * GWAVES)
+#endif
+#ifndef DL_DBG_RTHREADS
+#define DL_DBG_RTHREADS THREADS
+#endif
+constexpr int NSLOT = DL_DBG_NSLOT;
+constexpr int PB_STRIDE = LDH;                        // partial rows [NSLOT][132] from L_A on: 135 KB <= A + B + C + W
+static_assert(NSLOT * PB_STRIDE <= L_W + UNIT, "partial-sum buffer must fit the P, Q, H, W2' regions");
+
+struct SlotPlan {
+    int g, q;
 };
-
-template <bool EQUIV, int PREC>
-__device__ __forceinline__ Spill edge_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask,
-                                            int N, float norm_constant, float sa, float acc_scale, float inv_scale) {
-    const int c = lane & 31, hh = lane >> 5;
-    const int npairs = nb * nb;
-    const int ntiles = (npairs + 31) >> 5;
-    // static, contiguous, share-weighted tile ranges in wave order (the deterministic reduction below needs them)
-    constexpr int SH0 = DL_SHARE0, SH1 = DL_SHARE1, SH2 = (NWAVES > 8) ? DL_SHARE2 : 0;
-    constexpr int SH_TOT = 4 * (SH0 + SH1 + SH2);
-    const int grp = w >> 2;
-    const int my_sh = (grp == 0) ? SH0 : (grp == 1) ? SH1 : SH2;
-    const int cum0 = ((grp == 0) ? 0 : (grp == 1) ? 4 * SH0 : 4 * (SH0 + SH1)) + (w & 3) * my_sh;
-    const int cum1 = cum0 + my_sh;
-    const int t_begin = (cum0 * ntiles) / SH_TOT, t_end = (cum1 * ntiles) / SH_TOT;
-    Spill sp;
-    sp.row = (w > 0 && t_begin < t_end) ? (32 * t_begin) / nb : -1;
-    sp.v[0] = sp.v[1] = sp.v[2] = sp.v[3] = 0.0f;
-    float bias[4], w7[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        bias[nt] = v.vec[2 * HID + 32 * nt + c];
-        w7[nt] = EQUIV ? v.vec[3 * HID + 32 * nt + c] : 0.0f;
-    }
-    const float4* wrp = reinterpret_cast<const float4*>(v.vec + 64 * hh);
-    const float4* wdp = reinterpret_cast<const float4*>(v.vec + HID + 64 * hh);
-    const float4* Wp = reinterpret_cast<const float4*>(v.W) + (64 * hh * 32 + c);
-    if (!EQUIV) {
-        // zero the aggregate rows of the atoms whose FIRST pair lies in this wave's range: every row is zeroed exactly
-        // once, by the first wave that can touch it, in that wave's own program order - no workgroup barrier needed
-        const int r0 = (32 * t_begin + nb - 1) / nb;
-        const int r1 = min((32 * t_end - 1) / nb, nb - 1);
-        for (int row = r0; row <= r1; ++row) {
-            v.C[row * LDH + lane] = 0.0f;
-            v.C[row * LDH + 64 + lane] = 0.0f;
-        }
-    }
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const int p = 32 * t + c;
-        const bool valid = p < npairs;
-        const int pp = valid ? p : 0;
-        const int i = pp / nb;
-        const int j = pp - i * nb;
-        const int i_first = (32 * t) / nb;                       // wave-uniform
-        const int i_last = min(32 * t + 31, npairs - 1) / nb;    // wave-uniform
-        const float4 xi = *reinterpret_cast<const float4*>(v.xs + 4 * i);
-        const float4 xj = *reinterpret_cast<const float4*>(v.xs + 4 * j);
-        const float4 yi = *reinterpret_cast<const float4*>(v.x0 + 4 * i);
-        const float4 yj = *reinterpret_cast<const float4*>(v.x0 + 4 * j);
-        const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
-        const float r = dx * dx + dy * dy + dz * dz;             // squared distance, current x  (egnn.py:298)
-        const float d0 = ex * ex + ey * ey + ez * ez;            // squared distance at forward entry (:220)
-        float m = 0.0f;
-        if (valid) m = emask ? float(emask[v.idx[i] * N + v.idx[j]]) : 1.0f;
-
-        // f16x3: the accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
-        floatx16 acc0 = splat16(PREC == 0 ? bias[0] : 0.0f), acc1 = splat16(PREC == 0 ? bias[1] : 0.0f),
-                 acc2 = splat16(PREC == 0 ? bias[2] : 0.0f), acc3 = splat16(PREC == 0 ? bias[3] : 0.0f);
-        if constexpr (PREC == 0) {
-            // ---- first edge layer, generated as MFMA A-fragments: lane = (pair c, k = 64*hh + s).  Kept as a
-            // separate VALU phase (sched_barrier) so the MFMA loop below is a dense matrix-pipe stream that one
-            // wave can keep saturated while the SIMD's other wave is in its VALU phases.
-            float a[64];
-            {
-                const float4* Pp = reinterpret_cast<const float4*>(v.A + i * LDH + 64 * hh);
-                const float4* Qp = reinterpret_cast<const float4*>(v.B + j * LDH + 64 * hh);
-    #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float4 P = Pp[q], Q = Qp[q], wr = wrp[q], wd = wdp[q];
-                    a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
-                    a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
-                    a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
-                    a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- second edge layer: [32 pairs x 128] = A[32 x 128] * W2'^T, 4 feature tiles, exact fp32 MFMA;
-            // B fragments (one ds_read_b128 per k-step) run two steps ahead of their MFMAs
-            {
-                float4 b0 = Wp[0], b1 = Wp[32];
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    #pragma unroll
-                for (int s = 0; s < 64; ++s) {
-                    float4 b2 = b1;
-                    if (s + 2 < 64) b2 = Wp[(s + 2) * 32];
-                    acc0 = mfma32(a[s], b0.x, acc0);
-                    acc1 = mfma32(a[s], b0.y, acc1);
-                    acc2 = mfma32(a[s], b0.z, acc2);
-                    acc3 = mfma32(a[s], b0.w, acc3);
-                    b0 = b1; b1 = b2;
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read_b128 of step s+2 ...
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);   // ... ahead of the 4 MFMAs of step s
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            // ---- first edge layer as fp16 hi/lo A-fragments: lane = (pair c, k = 16*slab + 8*hh + e)
-            uint4 ah[8], al[8];
-            {
-                const float* Pp = v.A + i * LDH + 8 * hh;
-                const float* Qp = v.B + j * LDH + 8 * hh;
-                const float* wrb = v.vec + 8 * hh;
-                const float* wdb = v.vec + HID + 8 * hh;
-#pragma unroll
-                for (int slab = 0; slab < 8; ++slab) {
-                    float u[8];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int k0 = 16 * slab + 4 * q;
-                        const float4 P = *reinterpret_cast<const float4*>(Pp + k0);
-                        const float4 Q = *reinterpret_cast<const float4*>(Qp + k0);
-                        const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
-                        const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
-                        u[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x))) * sa;
-                        u[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y))) * sa;
-                        u[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z))) * sa;
-                        u[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w))) * sa;
-                    }
-                    split8(u, ah[slab], al[slab]);
-                }
-            }
-            // ---- second edge layer on the fp16 matrix pipe: per 16-k slab, 4 feature tiles x 3 split terms
-            const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane;
-#pragma unroll
-            for (int slab = 0; slab < 8; ++slab) {
-                uint4 bh[4], bl[4];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    bh[nt] = Wq[(slab * 4 + nt) * 64];
-                    bl[nt] = Wq[((8 + slab) * 4 + nt) * 64];
-                }
-                acc0 = mfma_h(al[slab], bh[0], acc0); acc1 = mfma_h(al[slab], bh[1], acc1);
-                acc2 = mfma_h(al[slab], bh[2], acc2); acc3 = mfma_h(al[slab], bh[3], acc3);
-                acc0 = mfma_h(ah[slab], bl[0], acc0); acc1 = mfma_h(ah[slab], bl[1], acc1);
-                acc2 = mfma_h(ah[slab], bl[2], acc2); acc3 = mfma_h(ah[slab], bl[3], acc3);
-                acc0 = mfma_h(ah[slab], bh[0], acc0); acc1 = mfma_h(ah[slab], bh[1], acc1);
-                acc2 = mfma_h(ah[slab], bh[2], acc2); acc3 = mfma_h(ah[slab], bh[3], acc3);
-            }
-            // back to the unscaled pre-activation (exact: inv_scale is a power of two)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                acc0[reg] = fmaf(acc0[reg], inv_scale, bias[0]); acc1[reg] = fmaf(acc1[reg], inv_scale, bias[1]);
-                acc2[reg] = fmaf(acc2[reg], inv_scale, bias[2]); acc3[reg] = fmaf(acc3[reg], inv_scale, bias[3]);
-            }
-        }
-        // ---- epilogue in the accumulator layout: lane holds feature 32*nt + c of 16 pairs (rows)
-        if (!EQUIV) {
-            // mask values of this lane's 16 rows: the pair lanes publish their int8 mask in a per-wave LDS
-            // strip, every lane reads back 4 words = rows {0-3, 8-11, 16-19, 24-27} + 4*hh (no ds_bpermute)
-            float mr[16];
-            {
-                signed char* strip = v.mscr + 32 * w;
-                if (hh == 0) strip[c] = (signed char)m;
-                const int* sw = reinterpret_cast<const int*>(strip) + hh;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int word = sw[2 * k];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) mr[4 * k + b] = float((signed char)(word >> (8 * b)));
-                }
-            }
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                acc0[reg] = silu_u(acc0[reg]);
-                acc1[reg] = silu_u(acc1[reg]);
-                acc2[reg] = silu_u(acc2[reg]);
-                acc3[reg] = silu_u(acc3[reg]);
-            }
-            const int p0 = 32 * t + 4 * hh;
-            for (int ii = i_first; ii <= i_last; ++ii) {         // 1-2 atoms per tile when n_b >= 32
-                const int lo = ii * nb - p0;                      // row r belongs to atom ii  <=>  lo <= r' < lo + nb
-                float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int rr = (reg & 3) + 8 * (reg >> 2);    // row index minus 4*hh
-                    const float wgt = (unsigned(rr - lo) < unsigned(nb)) ? mr[reg] : 0.0f;
-                    s0 = fmaf(wgt, acc0[reg], s0);
-                    s1 = fmaf(wgt, acc1[reg], s1);
-                    s2 = fmaf(wgt, acc2[reg], s2);
-                    s3 = fmaf(wgt, acc3[reg], s3);
-                }
-                s0 = xor32_sum(s0);
-                s1 = xor32_sum(s1);
-                s2 = xor32_sum(s2);
-                s3 = xor32_sum(s3);
-                if (ii == sp.row) {
-                    sp.v[0] += s0; sp.v[1] += s1; sp.v[2] += s2; sp.v[3] += s3;
-                } else if (hh == 0) {
-                    float* dst = v.C + ii * LDH + c;                 // only this wave ever touches row ii here
-                    dst[0] += s0; dst[32] += s1; dst[64] += s2; dst[96] += s3;
-                }
-            }
-        } else {
-            // s_row = sum_f w7'[f] * u2[row][f]: 4 in-lane terms, then a DPP/permlane sum over the 32 lanes of the half;
-            // lane c owns pair c = row c, whose scalar lives in half (c>>2)&1, register (c&3) + 4*(c>>3)
-            const bool want_hi = ((c >> 2) & 1) != 0;
-            const int my_reg = (c & 3) + 4 * (c >> 3);
-            float s_own = 0.0f;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float ts = w7[0] * silu_u(acc0[reg]);
-                ts = fmaf(w7[1], silu_u(acc1[reg]), ts);
-                ts = fmaf(w7[2], silu_u(acc2[reg]), ts);
-                ts = fmaf(w7[3], silu_u(acc3[reg]), ts);
-                ts = half32_allsum(ts);
-                float lo, hi;
-                both_halves(ts, lo, hi);
-                s_own = (reg == my_reg) ? (want_hi ? hi : lo) : s_own;
-            }
-            // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
-            const float den = sqrtf(r + 1e-8f) + norm_constant;
-            const float f = (hh == 0 && valid) ? s_own * m : 0.0f;
-            const float tx = (dx / den) * f, ty = (dy / den) * f, tz = (dz / den) * f;
-            for (int ii = i_first; ii <= i_last; ++ii) {
-                // fixed-order sum over the 32 pair lanes (the upper half contributes zeros)
-                const float ax = half32_allsum((i == ii) ? tx : 0.0f);
-                const float ay = half32_allsum((i == ii) ? ty : 0.0f);
-                const float az = half32_allsum((i == ii) ? tz : 0.0f);
-                if (ii == sp.row) {
-                    sp.v[0] += ax; sp.v[1] += ay; sp.v[2] += az;
-                } else if (lane == 0) {
-                    v.aggx[4 * ii + 0] += ax; v.aggx[4 * ii + 1] += ay; v.aggx[4 * ii + 2] += az;
-                }
-            }
-        }
-    }
+__device__ __forceinline__ SlotPlan slot_plan(int nb) {
+    SlotPlan sp;
+    sp.g = min(NSLOT / nb, nb);
+    sp.q = (nb + sp.g - 1) / sp.g;
     return sp;
 }
 
-// fold the per-wave first-atom partial sums into the aggregate, in wave order (deterministic).
-// Staging area: the first NWAVES rows of v.A (P is dead once every wave has left the edge phase).
-__device__ __forceinline__ void spill_publish(const Lds& v, const Spill& sp, int w, int lane, bool equiv) {
-    const int c = lane & 31, hh = lane >> 5;
-    if (lane == 0) v.misc[4 + w] = sp.row;
-    if (sp.row >= 0) {
-        if (!equiv) {
-            if (hh == 0) {
+// fp16 hi (truncated) / lo (nearest) fragments of 8 scaled values; the hi part as fp32 is the value with its low 13
+// mantissa bits cleared (v_and), which equals what v_cvt_pkrtz keeps for everything in the normal fp16 range
+__device__ __forceinline__ void split8t(const float (&u)[8], uint4& hi, uint4& lo) {
+    unsigned h[4], l[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) v.A[w * LDH + 32 * nt + c] = sp.v[nt];
+    for (int q = 0; q < 4; ++q) {
+        const float a = u[2 * q], b = u[2 * q + 1];
+        const float ah = __uint_as_float(__float_as_uint(a) & 0xffffe000u), bh = __uint_as_float(__float_as_uint(b) & 0xffffe000u);
+        h[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ah, bh));
+        l[q] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - ah, b - bh));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <bool EQUIV, int PREC>
+__device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask, int N,
+                                           float norm_constant, float sa, float inv_scale, const float* __restrict__ sc) {
+    const int c = lane & 31, hh = lane >> 5;
+    const SlotPlan pl = slot_plan(nb);
+    const int q = pl.q;
+    const int slot = 32 * w + c;
+    const bool slot_ok = slot < nb * pl.g;
+    const int i = slot_ok ? slot / pl.g : 0;
+    const int j0 = slot_ok ? (slot - i * pl.g) * q : 0;
+    const int jn = slot_ok ? min(q, nb - j0) : 0;                 // senders this slot really has (may be <= 0)
+    const bool wave_active = 32 * w < nb * pl.g;                  // wave-uniform
+    float* pb = v.A + slot * PB_STRIDE;
+
+    floatx16 agg[4];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) agg[mt] = splat16(0.0f);
+
+    if (wave_active) {
+        const float4 xi = *reinterpret_cast<const float4*>(v.xs + 4 * i);
+        const float4 yi = *reinterpret_cast<const float4*>(v.x0 + 4 * i);
+        const int8_t* mrow = emask ? emask + v.idx[i] * N : nullptr;
+        const float* Pp_ = v.A + i * LDH + 4 * hh;
+        const float* bias_p_ = v.vec + 2 * HID + 4 * hh;
+        const float* w7_p_ = v.vec + 3 * HID + 4 * hh;
+        const float isa = inv_pow2(sa);
+
+        // rank-2 geometric term wr'[f] r + wd'[f] d0 as an MFMA: k-slots of half 0 carry r, of half 1 carry d0
+        float ga[4];                 // fp32: A operand (k = hh)
+        uint4 gaf[4];                // f16x3: A fragments {hi, lo | hi, 0 | 0 ...} x {hi, hi | lo, 0 | 0 ...} of the pair side
+        float sX = 1.0f, invS1 = 1.0f;
+        if constexpr (PREC == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) ga[mt] = v.vec[(hh ? HID : 0) + 32 * mt + c];
+        } else {
+            const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+            const float s_wr = scale_for(sc[6]), s_wd = scale_for(sc[7]);
+            const float S1 = fminf(scale_for(4.0f * x2) * s_wr, scale_for(4.0f * x02) * s_wd);
+            invS1 = inv_pow2(S1);
+            sX = S1 * inv_pow2(hh ? s_wd : s_wr);
+            const float s_w = hh ? s_wd : s_wr;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float wv = v.vec[(hh ? HID : 0) + 32 * mt + c] * s_w;
+                const float wh = __uint_as_float(__float_as_uint(wv) & 0xffffe000u);
+                const unsigned d0w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(wh, wv - wh));
+                const unsigned d1w = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(wh, 0.0f));
+                gaf[mt] = make_uint4(d0w, d1w, 0u, 0u);
             }
-        } else if (lane == 0) {
-            v.A[w * LDH + 0] = sp.v[0]; v.A[w * LDH + 1] = sp.v[1]; v.A[w * LDH + 2] = sp.v[2];
+        }
+
+        auto load_mask = [&](int t) -> float {
+            if (t >= jn) return 0.0f;
+            return mrow ? float(mrow[v.idx[j0 + t]]) : 1.0f;
+        };
+        float m_next = load_mask(0);
+
+        for (int t = 0; t < q; ++t) {
+            // the P row, the bias vectors and all of W2' do not depend on t: without an opaque offset the compiler hoists
+            // ~100 LDS reads out of the loop into registers it does not have (= scratch) and reloads them every iteration
+            int opq = 0;
+            asm volatile("" : "+s"(opq));
+            const float* Pp = Pp_ + opq;
+            const float* bias_p = bias_p_ + opq;
+            const float* w7_p = w7_p_ + opq;
+            const bool ok = t < jn;
+            const int j = ok ? j0 + t : 0;
+            const float m = m_next;
+            m_next = load_mask(t + 1);
+            const float4 xj = *reinterpret_cast<const float4*>(v.xs + 4 * j);
+            const float4 yj = *reinterpret_cast<const float4*>(v.x0 + 4 * j);
+            const float dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
+            const float r = dx * dx + dy * dy + dz * dz;             // squared distance, current x  (egnn.py:298)
+            const float d0 = ex * ex + ey * ey + ez * ez;            // squared distance at forward entry (:220)
+            const float* Qp = v.B + j * LDH + 4 * hh;
+
+            // ---- first edge layer, transposed: a1[mt][reg] = pre-activation of feature 32mt + (reg&3) + 8(reg>>2) + 4hh
+            floatx16 a1[4];
+            if constexpr (PREC == 0) {
+                const float X = hh ? d0 : r;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float4 P = *reinterpret_cast<const float4*>(Pp + 32 * mt + 8 * qq);
+                        const float4 Q = *reinterpret_cast<const float4*>(Qp + 32 * mt + 8 * qq);
+                        a1[mt][4 * qq + 0] = P.x + Q.x; a1[mt][4 * qq + 1] = P.y + Q.y;
+                        a1[mt][4 * qq + 2] = P.z + Q.z; a1[mt][4 * qq + 3] = P.w + Q.w;
+                    }
+                    a1[mt] = mfma32(ga[mt], X, a1[mt]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) a1[mt][reg] = silu_u(a1[mt][reg]);
+            } else {
+                const float xv = (hh ? d0 : r) * sX;
+                const float xh_ = __uint_as_float(__float_as_uint(xv) & 0xffffe000u);
+                const uint4 xf = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xh_, xh_)),
+                                            __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xv - xh_, 0.0f)), 0u, 0u);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) a1[mt] = mfma_h(gaf[mt], xf, splat16(0.0f));
+            }
+
+            // ---- f16x3: SiLU + split into the B fragments of the second layer (slab s = registers 8(s&1).. of tile s>>1)
+            uint4 bh[8], bl[8];
+            if constexpr (PREC == 1) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        float u[8];
+#pragma unroll
+                        for (int qq = 0; qq < 2; ++qq) {
+                            const float4 P = *reinterpret_cast<const float4*>(Pp + 32 * mt + 16 * half + 8 * qq);
+                            const float4 Q = *reinterpret_cast<const float4*>(Qp + 32 * mt + 16 * half + 8 * qq);
+                            const float pq[4] = {P.x + Q.x, P.y + Q.y, P.z + Q.z, P.w + Q.w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float y = fmaf(a1[mt][8 * half + 4 * qq + k], invS1, pq[k]);
+                                // SiLU in u-form, scaled into the fp16 range: y * sa / (1 + 2^y)
+                                u[4 * qq + k] = y * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(y), isa, isa));
+                            }
+                        }
+                        split8t(u, bh[2 * mt + half], bl[2 * mt + half]);
+                    }
+                }
+            }
+
+            // ---- second edge layer, transposed: D2[f][pair] = sum_k W2'[f][k] u[k][pair]
+            float ssum = 0.0f;
+            auto epilogue = [&](const floatx16& c2, int mt) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bias_p + 32 * mt + 8 * qq);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    float ww[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (EQUIV) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(w7_p + 32 * mt + 8 * qq);
+                        ww[0] = w4.x; ww[1] = w4.y; ww[2] = w4.z; ww[3] = w4.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int reg = 4 * qq + k;
+                        const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
+                        const float u2 = silu_u(y2);
+                        if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
+                        else ssum = fmaf(ww[k], u2, ssum);
+                    }
+                }
+            };
+            if constexpr (PREC == 0) {
+                floatx16 c2[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(bias_p + 32 * mt + 8 * qq);
+                        c2[mt][4 * qq] = b4.x; c2[mt][4 * qq + 1] = b4.y; c2[mt][4 * qq + 2] = b4.z; c2[mt][4 * qq + 3] = b4.w;
+                    }
+                const float4* Wp = reinterpret_cast<const float4*>(v.W) + lane + opq;
+#pragma unroll
+                for (int s2 = 0; s2 < 64; ++s2) {
+                    const float4 a4 = Wp[s2 * 64];
+                    const float bv = a1[s2 >> 4][s2 & 15];
+                    c2[0] = mfma32(a4.x, bv, c2[0]);
+                    c2[1] = mfma32(a4.y, bv, c2[1]);
+                    c2[2] = mfma32(a4.z, bv, c2[2]);
+                    c2[3] = mfma32(a4.w, bv, c2[3]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) epilogue(c2[mt], mt);
+            } else {
+                const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane + opq;
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh) {
+                    floatx16 c0 = splat16(0.0f), c1 = splat16(0.0f);
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        const uint4 ah0 = Wq[(s * 4 + 2 * mh) * 64], ah1 = Wq[(s * 4 + 2 * mh + 1) * 64];
+                        const uint4 al0 = Wq[((8 + s) * 4 + 2 * mh) * 64], al1 = Wq[((8 + s) * 4 + 2 * mh + 1) * 64];
+                        c0 = mfma_h(al0, bh[s], c0); c1 = mfma_h(al1, bh[s], c1);
+                        c0 = mfma_h(ah0, bl[s], c0); c1 = mfma_h(ah1, bl[s], c1);
+                        c0 = mfma_h(ah0, bh[s], c0); c1 = mfma_h(ah1, bh[s], c1);
+                    }
+                    epilogue(c0, 2 * mh);
+                    epilogue(c1, 2 * mh + 1);
+                }
+            }
+            if (EQUIV) {
+                // s = w7'.u2 over all 128 features: this lane summed its half's 64, the other half holds the rest
+                float lo, hi;
+                both_halves(ssum, lo, hi);
+                const float s_all = lo + hi;
+                // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
+                const float den = sqrtf(r + 1e-8f) + norm_constant;
+                const float f = ok ? s_all * m : 0.0f;
+                ax += (dx / den) * f; ay += (dy / den) * f; az += (dz / den) * f;
+            }
+        }
+    }
+    lds_barrier();                         // every wave left the loop: P (v.A), Q (v.B), v.W are dead -> partial sums
+    if (slot_ok) {
+        if (!EQUIV) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    *reinterpret_cast<float4*>(pb + 32 * mt + 8 * qq + 4 * hh) =
+                        make_float4(agg[mt][4 * qq], agg[mt][4 * qq + 1], agg[mt][4 * qq + 2], agg[mt][4 * qq + 3]);
+        } else if (hh == 0) {
+            // compact [slot][4] triples inside the P region: H (v.C) must survive a coordinate pass
+            *reinterpret_cast<float4*>(v.A + 4 * slot) = make_float4(ax, ay, az, 0.0f);
         }
     }
 }
 
-__device__ __forceinline__ void spill_reduce(const Lds& v, int tid, bool equiv) {
-    const int width = equiv ? 3 : HID;
-    if (tid < width) {
-        for (int w = 1; w < NWAVES; ++w) {
-            const int row = v.misc[4 + w];
-            if (row >= 0) {
-                if (!equiv) v.C[row * LDH + tid] += v.A[w * LDH + tid];
-                else v.aggx[4 * row + tid] += v.A[w * LDH + tid];
+// sum of the slot partials of every atom, chunks in ascending order (deterministic).  GCL: each thread owns up to four
+// (atom, 4-feature) groups and returns them in registers (the destination v.C overlaps the partial buffer); max |agg|.
+struct AggRegs {
+    float4 v[4 * THREADS / DL_DBG_RTHREADS];
+};
+__device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out) {
+    const SlotPlan pl = slot_plan(nb);
+    float am = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4 * THREADS / DL_DBG_RTHREADS; ++k) {
+        const int e = tid + DL_DBG_RTHREADS * k;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < DL_DBG_RTHREADS && e < nb * 32) {
+            const float* src = v.A + (e >> 5) * pl.g * PB_STRIDE + 4 * (e & 31);
+            for (int ch = 0; ch < pl.g; ++ch) {
+                const float4 p = *reinterpret_cast<const float4*>(src + ch * PB_STRIDE);
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
             }
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
         }
+        out.v[k] = s;
+    }
+    return am;
+}
+__device__ __forceinline__ void pair_store_gcl(const Lds& v, int nb, int tid, const AggRegs& in) {
+#pragma unroll
+    for (int k = 0; k < 4 * THREADS / DL_DBG_RTHREADS; ++k) {
+        const int e = tid + DL_DBG_RTHREADS * k;
+        if (tid < DL_DBG_RTHREADS && e < nb * 32) *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = in.v[k];
+    }
+}
+// coordinate head: aggx[i][0..2] = sum of the slot triples
+__device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid) {
+    const SlotPlan pl = slot_plan(nb);
+    if (tid < nb) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int ch = 0; ch < pl.g; ++ch) {
+            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (tid * pl.g + ch));
+            sx += p.x; sy += p.y; sz += p.z;
+        }
+        v.aggx[4 * tid + 0] = sx; v.aggx[4 * tid + 1] = sy; v.aggx[4 * tid + 2] = sz;
     }
 }
 
 
-// f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
-constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, FM_X02 = 6;
 
 // scale of the edge-pass A-fragments: |u| <= |y| <= |P|+|Q| + r*|wr'| + d0*|wd'|,  r <= 4 max|x|^2
 __device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restrict__ sc) {
@@ -586,7 +602,6 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
                                          PreW& pw, const NextPass nx) {
     const float* vecs = g + G_VEC;
     const float* sc = g + G_SCALE;
-    Spill sp;
     float s_h;
     {   // ---- front: projections + pair loop
     const LaneIds q = lane_ids();
@@ -594,42 +609,39 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     prof_event(pf, w, lane, 10);
     if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; v.fmax[FM_T] = 0u; }
     s_h = (PREC == 1) ? scale_for(__uint_as_float(__builtin_amdgcn_readfirstlane(v.fmax[FM_H0 + par]))) : 1.0f;
-    if (grid_wave(w)) {
+    {
         // first-layer projections P,Q (fragments prefetched: `pw`; the W2' image is arriving by DMA)
         const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
-        if (LEAN) pw.bf = load_bfrag(g + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
         const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
         if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
     }
     prof_event(pf, w, lane, 11);
     dma_wait();
     lds_barrier();                         // P, Q, W2', vectors in place; every read of H (v.C) done
-    prof_event(pf, w, lane, 12);           // (the aggregate rows are zeroed inside edge_phase, by the wave that starts them)
+    prof_event(pf, w, lane, 12);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
-    sp = edge_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, accs, inv_pow2(accs));
+    pair_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc);     // ends with the partial rows in LDS
     prof_event(pf, w, lane, 13);
     }
     // ---- back: aggregate completion + node MLP (lane indices re-derived, see lane_ids)
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
-    const bool active = grid_wave(w) && ((mt == 0) || (nb > 32));
-    lds_barrier();                         // every wave left the edge phase: P (v.A), Q (v.B), v.W, v.vec dead
-    if (grid_wave(w)) stage_next(v, nx, w, tid);                   // next pass's W2' image: DMA under the node phases
-    if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
-    spill_publish(v, sp, w, lane, false);
-    lds_barrier();
-    spill_reduce(v, tid, false);
-    lds_barrier();                         // aggregate complete in v.C
-    if (grid_wave(w)) {
+    const bool active = (mt == 0) || (nb > 32);
+    lds_barrier();                         // partial rows complete
+    {
+        AggRegs ar;
+        const float am = pair_reduce_gcl(v, nb, tid, ar);
+        lds_barrier();                     // every partial read: P, Q, H, W2' regions are free
+        stage_next(v, nx, w, tid);         // next pass's W2' image: DMA under the node phases
+        if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
+        pair_store_gcl(v, nb, tid, ar);    // aggregate -> v.C
+        if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
+    }
+    {
         touch16(hown);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) store_row(v, v.A, 32 * mt + acc_row(reg, hh), nb, 32 * nt + c, hown[reg]);
-    }
-    if (PREC == 1) {
-        float am = 0.0f;
-        for (int e = tid; e < nb * HID; e += THREADS) am = fmaxf(am, fabsf(v.C[(e >> 7) * LDH + (e & (HID - 1))]));
-        block_max(&v.fmax[FM_AGG], am, lane);
     }
     lds_barrier();
     prof_event(pf, w, lane, 14);
@@ -639,8 +651,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
         // fragments requested at the point of use: issued earlier they do not fit beside the h tile, and the register
         // allocator then waits for them just to spill them (measured: early prefetch 3.48-3.53 M ticks, this 3.38 M)
         BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
-        BFrag b3b;
-        if (!LEAN) b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+        BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
         const float b3 = vecs[4 * HID + 32 * nt + c];
         float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
         if (PREC == 1) {
@@ -651,8 +662,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
         floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
         const int arow = min(32 * mt + c, nb - 1);
         gemm_k128<PREC>(acc, v.A, arow, hh, b3a, s1);
-        if (LEAN) b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
-        else b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);    // for layer 2, under layer 1's second GEMM
+        b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);         // for layer 2, under layer 1's second GEMM
         gemm_k128<PREC>(acc, v.C, arow, hh, b3b, s2);
         float tmax = 0.0f;
 #pragma unroll
@@ -667,9 +677,8 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     prof_event(pf, w, lane, 15);
     lds_barrier();
     // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
-    if (!LEAN && grid_wave(w)) load_next(pw, nx, w, lane);         // the next pass's projection fragments, under layer 2
+    load_next(pw, nx, w, lane);            // the next pass's projection fragments, under layer 2
     if (active) {
-        if (LEAN) b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
         const float b4 = vecs[5 * HID + 32 * nt + c];
         float s_t = 1.0f, inv = 1.0f;
         if (PREC == 1) { s_t = scale_for(__uint_as_float(v.fmax[FM_T])); inv = inv_pow2(s_t * sc[4]); }
@@ -706,37 +715,33 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
                                            int par, PreW& pw, const NextPass nx) {
     const float* vecs = e + E_VEC;
     const float* sc = e + E_SCALE;
-    Spill sp;
     {   // ---- front: projections + pair loop
     const LaneIds q = lane_ids();
-    const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, nt = q.nt;
+    const int w = q.w, lane = q.lane, c = q.c, nt = q.nt;
     prof_event(pf, w, lane, 30);
-    if (grid_wave(w)) {
+    {
         const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
         const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
-        if (LEAN) pw.bf = load_bfrag(e + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
         const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
         if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
     }
-    if (tid < 4 * nb) v.aggx[tid] = 0.0f;
     prof_event(pf, w, lane, 31);
     dma_wait();
     lds_barrier();
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
-    sp = edge_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, accs, inv_pow2(accs));
+    pair_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc);   // ends with the partial triples in LDS
     prof_event(pf, w, lane, 33);
     }
     // ---- back: coordinate update (lane indices re-derived, see lane_ids)
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane;
-    if (!LEAN && grid_wave(w)) load_next(pw, nx, w, lane);         // next block's first pass, under the reduction
-    lds_barrier();
-    if (grid_wave(w)) stage_next(v, nx, w, tid);
-    spill_publish(v, sp, w, lane, true);
-    lds_barrier();
-    spill_reduce(v, tid, true);
+    load_next(pw, nx, w, lane);            // next block's first pass, under the reduction
+    lds_barrier();                         // partial triples complete
+    pair_reduce_equiv(v, nb, tid);
+    lds_barrier();                         // partials read: P, Q, W2' regions are free
+    stage_next(v, nx, w, tid);
     if (PREC == 1 && tid == 0) { v.fmax[FM_PQ] = 0u; v.fmax[FM_X2] = 0u; }
     lds_barrier();
     float n2 = 0.0f;
@@ -771,10 +776,10 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     }
 
     PreW pw;
-    if (grid_wave(w)) {                                             // first pass's weights (v.W, v.vec are free here)
+    {                                                               // first pass's weights (v.W, v.vec are free here)
         const NextPass first = {wp + OFF_BLOCKS, false};
         stage_next(v, first, w, tid);
-        if (!LEAN) load_next(pw, first, w, lane);
+        load_next(pw, first, w, lane);
     }
 
     // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
@@ -827,7 +832,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
         const int row = 32 * mt + acc_row(reg, hh);
-        hown[reg] = (grid_wave(w) && row < nb) ? v.C[row * LDH + 32 * nt + c] : 0.0f;
+        hown[reg] = (row < nb) ? v.C[row * LDH + 32 * nt + c] : 0.0f;
     }
     prof_event(pf, w, lane, 2);
 
@@ -1176,6 +1181,38 @@ double pack_lds_image_f16(float* dstf, const float* w, int ld, double scale) {
     return sw;
 }
 
+// ---- images of the LDS-resident pair loop (egnn_fc.hip: pair_phase), where the second edge layer is computed transposed:
+// W2' is the A operand (rows = output features) and its k-slots follow the accumulator layout of the first layer:
+// the lane half hh holds, in register reg of 32-feature tile mt1, input feature 32*mt1 + (reg&3) + 8*(reg>>2) + 4*hh.
+inline int feat_of(int mt1, int reg, int hh) { return 32 * mt1 + (reg & 3) + 8 * (reg >> 2) + 4 * hh; }
+
+// fp32: img[s2 = 16*mt1 + reg][lane][mt] = W[f = 32*mt + (lane&31)][k = feat_of(mt1, reg, lane>>5)]
+void pack_lds_image_t(float* dst, const float* w, int ld, double scale) {
+    for (int s2 = 0; s2 < 64; ++s2)
+        for (int lane = 0; lane < 64; ++lane)
+            for (int mt = 0; mt < 4; ++mt)
+                dst[(s2 * 64 + lane) * 4 + mt] =
+                    float(double(w[size_t(32 * mt + (lane & 31)) * ld + feat_of(s2 >> 4, s2 & 15, lane >> 5)]) * scale);
+}
+
+// f16x3: img[part*8 + slab][mt][lane][e], k-slot (slab, hh, e) = feat_of(slab>>1, 8*(slab&1) + e, hh)
+double pack_lds_image_f16_t(float* dstf, const float* w, int ld, double scale) {
+    const double sw = f16_weight_scale(w, ld, 0, HID, scale);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
+    for (int slab = 0; slab < 8; ++slab)
+        for (int mt = 0; mt < 4; ++mt)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 32 * mt + (lane & 31);
+                    const int k = feat_of(slab >> 1, 8 * (slab & 1) + e, lane >> 5);
+                    uint16_t hi, lo;
+                    split_f16(double(w[size_t(f) * ld + k]) * scale * sw, hi, lo);
+                    dst[(((slab * 4 + mt) * 64 + lane) * 8) + e] = hi;
+                    dst[((((8 + slab) * 4 + mt) * 64 + lane) * 8) + e] = lo;
+                }
+    return sw;
+}
+
 float vec_absmax(const float* v) {
     float m = 0.0f;
     for (int f = 0; f < HID; ++f) m = fmaxf(m, fabsf(v[f]));
@@ -1251,6 +1288,10 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         pack_lds_image(d, ww, ld, sc);
         return 1.0f;
     };
+    auto image_t = [&](float* d, const float* ww, int ld, double sc) {     // same scale as image(): one sc[] slot serves both
+        if (f16) (void)pack_lds_image_f16_t(d, ww, ld, sc);
+        else pack_lds_image_t(d, ww, ld, sc);
+    };
     const double c = -1.4426950408889634;            // -log2(e): y = c * pre-activation
     const double inv_norm = 1.0 / double(cfg->normalization_factor);
     int ti = 0;
@@ -1281,6 +1322,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             sc[3] = unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);      // agg arrives as c*norm*true agg
             sc[4] = unit(g + G_W4, w4, HID, 0, 1.0 / c);
             sc[5] = image(g + G_W2, w2, HID, 1.0);
+            image_t(g + G_W2T, w2, HID, 1.0);
             float* vv = g + G_VEC;
             pack_vec(vv + 0 * HID, b1, 1, c);
             pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);             // radial column
@@ -1300,6 +1342,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         sc[0] = unit(e + E_W5A, w5, ld5, 0, c);
         sc[1] = unit(e + E_W5B, w5, ld5, HID, c);
         sc[2] = image(e + E_W6, w6, HID, 1.0);
+        image_t(e + E_W6T, w6, HID, 1.0);
         float* vv = e + E_VEC;
         pack_vec(vv + 0 * HID, b5, 1, c);
         pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);

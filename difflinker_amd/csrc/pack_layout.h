@@ -27,16 +27,17 @@ constexpr int OFF_EMB_B = OFF_EMB_W + HID * FINP;     // [128]
 constexpr int OFF_OUT_W = OFF_EMB_B + HID;            // [16][128]
 constexpr int OFF_OUT_B = OFF_OUT_W + 16 * HID;       // [16]
 constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
-// GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image), vectors
-constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT;
-constexpr int G_VEC = 6 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
+// GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image of the sparse kernels: pairs are the
+// MFMA rows), W2' again as the LDS image of the LDS-resident kernels (features are the MFMA rows, see egnn_fc.hip), vectors
+constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT, G_W2T = 6 * UNIT;
+constexpr int G_VEC = 7 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
 constexpr int G_SCALE = G_VEC + 6 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max
-constexpr int GCL_SIZE = 6 * UNIT + 6 * HID + 8;
-// equivariant update: units W5a', W5b', W6' (LDS image), vectors
-constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT;
-constexpr int E_VEC = 3 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
+constexpr int GCL_SIZE = 7 * UNIT + 6 * HID + 8;
+// equivariant update: units W5a', W5b', W6' (both LDS images), vectors
+constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT, E_W6T = 3 * UNIT;
+constexpr int E_VEC = 4 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
 constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max
-constexpr int EQ_SIZE = 3 * UNIT + 5 * HID + 8;
+constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + 8;
 constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
 
 struct ModelDims {
