@@ -109,6 +109,15 @@ __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
 #endif
 }
 
+// events INSIDE the pair loop perturb it (the profile state lives across the loop): -DDL_PROFILE_LOOP builds only
+__device__ __forceinline__ void loop_event(Prof& pf, int w, int lane, int tag) {
+#ifdef DL_PROFILE_LOOP
+    prof_event(pf, w, lane, tag);
+#else
+    (void)pf; (void)w; (void)lane; (void)tag;
+#endif
+}
+
 // ---- f16x3 path (PREC 1): every fp32 operand of a 128-wide contraction is scaled by a power of two into the
 // fp16 range and split x*s = hi + lo (both fp16); a product is taken as hi*hi' + hi*lo' + lo*hi' on the fp16
 // matrix pipe (v_mfma_f32_32x32x16_f16, fp32 accumulate) and the accumulator is scaled back exactly.  The
@@ -287,13 +296,7 @@ constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, 
 //   EQUIV = true : aggx[i]    = sum_j cdiff_ij * (w7'.u2_ij) * m_ij (coordinate head)      -> partial triples
 // The partials of the g slots of an atom are written to LDS (over P, Q, H and W2', dead by then) after the barrier that
 // ends the loop; pair_reduce_* adds them in chunk order.
-#ifndef DL_DBG_NSLOT
-#define DL_DBG_NSLOT (32 * GWAVES)
-#endif
-#ifndef DL_DBG_RTHREADS
-#define DL_DBG_RTHREADS THREADS
-#endif
-constexpr int NSLOT = DL_DBG_NSLOT;
+constexpr int NSLOT = 32 * GWAVES;
 constexpr int PB_STRIDE = LDH;                        // partial rows [NSLOT][132] from L_A on: 135 KB <= A + B + C + W
 static_assert(NSLOT * PB_STRIDE <= L_W + UNIT, "partial-sum buffer must fit the P, Q, H, W2' regions");
 
@@ -324,7 +327,8 @@ __device__ __forceinline__ void split8t(const float (&u)[8], uint4& hi, uint4& l
 
 template <bool EQUIV, int PREC>
 __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask, int N,
-                                           float norm_constant, float sa, float inv_scale, const float* __restrict__ sc) {
+                                           float norm_constant, float sa, float inv_scale, const float* __restrict__ sc,
+                                           Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
     const SlotPlan pl = slot_plan(nb);
     const int q = pl.q;
@@ -374,11 +378,15 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             }
         }
 
-        auto load_mask = [&](int t) -> float {
-            if (t >= jn) return 0.0f;
-            return mrow ? float(mrow[v.idx[j0 + t]]) : 1.0f;
+        // mask value of step t (0 past the end of the slot's range); the raw byte is converted where it is used, so the
+        // wait for the load lands there and not right behind its issue
+        auto load_mask = [&](int t) -> int {
+            if (mrow == nullptr) return (t < jn) ? 1 : 0;
+            const int jj = (t < jn) ? j0 + t : j0;                 // always a valid row (the slot is empty when jn <= 0)
+            const int raw = (jn > 0) ? int(mrow[v.idx[min(jj, nb - 1)]]) : 0;
+            return (t < jn) ? raw : 0;
         };
-        float m_next = load_mask(0);
+        int m_next = load_mask(0);
 
         for (int t = 0; t < q; ++t) {
             // the P row, the bias vectors and all of W2' do not depend on t: without an opaque offset the compiler hoists
@@ -390,7 +398,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             const float* w7_p = w7_p_ + opq;
             const bool ok = t < jn;
             const int j = ok ? j0 + t : 0;
-            const float m = m_next;
+            const int m_raw = m_next;
             m_next = load_mask(t + 1);
             const float4 xj = *reinterpret_cast<const float4*>(v.xs + 4 * j);
             const float4 yj = *reinterpret_cast<const float4*>(v.x0 + 4 * j);
@@ -399,10 +407,51 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             const float r = dx * dx + dy * dy + dz * dz;             // squared distance, current x  (egnn.py:298)
             const float d0 = ex * ex + ey * ey + ez * ez;            // squared distance at forward entry (:220)
             const float* Qp = v.B + j * LDH + 4 * hh;
+            float ssum = 0.0f;
 
-            // ---- first edge layer, transposed: a1[mt][reg] = pre-activation of feature 32mt + (reg&3) + 8(reg>>2) + 4hh
-            floatx16 a1[4];
+            // bias (and w7') vectors of a 32-feature tile: four broadcast float4 per lane
+            struct TileVecs { float4 b[4], w[4]; };
+            auto load_vecs = [&](int mt) {
+                TileVecs tv;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    tv.b[qq] = *reinterpret_cast<const float4*>(bias_p + 32 * mt + 8 * qq);
+                    if (EQUIV) tv.w[qq] = *reinterpret_cast<const float4*>(w7_p + 32 * mt + 8 * qq);
+                }
+                return tv;
+            };
+            // the loaded values exist HERE (the compiler otherwise sinks each broadcast read next to its first use and waits for
+            // it there: eight exposed LDS latencies per half tile)
+            auto keep_vecs = [&](TileVecs& tv) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    asm volatile("" : "+v"(tv.b[qq].x), "+v"(tv.b[qq].y), "+v"(tv.b[qq].z), "+v"(tv.b[qq].w));
+                    if (EQUIV) asm volatile("" : "+v"(tv.w[qq].x), "+v"(tv.w[qq].y), "+v"(tv.w[qq].z), "+v"(tv.w[qq].w));
+                }
+            };
+            // SiLU + mask + sum over senders (GCL) / w7' dot (coordinate head) of one 32-feature tile of D2
+            auto epilogue = [&](const floatx16& c2, int mt, const TileVecs& tv, float m) {
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float bb[4] = {tv.b[qq].x, tv.b[qq].y, tv.b[qq].z, tv.b[qq].w};
+                    float ww[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (EQUIV) { ww[0] = tv.w[qq].x; ww[1] = tv.w[qq].y; ww[2] = tv.w[qq].z; ww[3] = tv.w[qq].w; }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int reg = 4 * qq + k;
+                        const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
+                        const float u2 = silu_u(y2);
+                        if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
+                        else ssum = fmaf(ww[k], u2, ssum);
+                    }
+                }
+            };
+
             if constexpr (PREC == 0) {
+                // ---- exact fp32: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate and blocks the VALU of both waves of the
+                // SIMD (profiles/r02/ubench_pair_overlap.log), so there is nothing to interleave: phases in dependency order.
+                // a1[mt][reg] = pre-activation of feature 32mt + (reg&3) + 8(reg>>2) + 4hh of this lane's pair
+                floatx16 a1[4];
                 const float X = hh ? d0 : r;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
@@ -419,63 +468,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int reg = 0; reg < 16; ++reg) a1[mt][reg] = silu_u(a1[mt][reg]);
-            } else {
-                const float xv = (hh ? d0 : r) * sX;
-                const float xh_ = __uint_as_float(__float_as_uint(xv) & 0xffffe000u);
-                const uint4 xf = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xh_, xh_)),
-                                            __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xv - xh_, 0.0f)), 0u, 0u);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) a1[mt] = mfma_h(gaf[mt], xf, splat16(0.0f));
-            }
-
-            // ---- f16x3: SiLU + split into the B fragments of the second layer (slab s = registers 8(s&1).. of tile s>>1)
-            uint4 bh[8], bl[8];
-            if constexpr (PREC == 1) {
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        float u[8];
-#pragma unroll
-                        for (int qq = 0; qq < 2; ++qq) {
-                            const float4 P = *reinterpret_cast<const float4*>(Pp + 32 * mt + 16 * half + 8 * qq);
-                            const float4 Q = *reinterpret_cast<const float4*>(Qp + 32 * mt + 16 * half + 8 * qq);
-                            const float pq[4] = {P.x + Q.x, P.y + Q.y, P.z + Q.z, P.w + Q.w};
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float y = fmaf(a1[mt][8 * half + 4 * qq + k], invS1, pq[k]);
-                                // SiLU in u-form, scaled into the fp16 range: y * sa / (1 + 2^y)
-                                u[4 * qq + k] = y * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(y), isa, isa));
-                            }
-                        }
-                        split8t(u, bh[2 * mt + half], bl[2 * mt + half]);
-                    }
-                }
-            }
-
-            // ---- second edge layer, transposed: D2[f][pair] = sum_k W2'[f][k] u[k][pair]
-            float ssum = 0.0f;
-            auto epilogue = [&](const floatx16& c2, int mt) {
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(bias_p + 32 * mt + 8 * qq);
-                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
-                    float ww[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (EQUIV) {
-                        const float4 w4 = *reinterpret_cast<const float4*>(w7_p + 32 * mt + 8 * qq);
-                        ww[0] = w4.x; ww[1] = w4.y; ww[2] = w4.z; ww[3] = w4.w;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int reg = 4 * qq + k;
-                        const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
-                        const float u2 = silu_u(y2);
-                        if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
-                        else ssum = fmaf(ww[k], u2, ssum);
-                    }
-                }
-            };
-            if constexpr (PREC == 0) {
+                // second layer, transposed: D2[f][pair] = b2'[f] + sum_k W2'[f][k] u[k][pair]
                 floatx16 c2[4];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -494,23 +487,113 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     c2[2] = mfma32(a4.z, bv, c2[2]);
                     c2[3] = mfma32(a4.w, bv, c2[3]);
                 }
+                const float m = float(m_raw);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) epilogue(c2[mt], mt);
+                for (int mt = 0; mt < 4; ++mt) {
+                    TileVecs tv = load_vecs(mt);
+                    epilogue(c2[mt], mt, tv, m);
+                }
             } else {
+                // ---- f16x3, software-pipelined IN the wave.  A wave issues at most one VALU instruction every ~4.6 cycles and
+                // is blocked at an MFMA while the matrix pipe is busy, so a phase-separated stream (all SiLUs, then all MFMAs)
+                // costs VALU time + MFMA time per wave, and the SIMD's second wave - running the same phases - hides little of
+                // it (measured: 10.8 K cycles per step alone, 16.6 K with the partner; profiles/r02).  Here the first layer is
+                // produced one 32-feature tile (two k-slabs) at a time and the 24 MFMAs that consume tile k are issued one by
+                // one BETWEEN the three VALU chunks of each element pair of tile k+1; sched_barrier after every chunk pins the
+                // order.  Fragments are double-buffered (2 x 16 registers), W2' fragments and P/Q rows arrive one group ahead.
+                const float xv = (hh ? d0 : r) * sX;
+                const float xh_ = __uint_as_float(__float_as_uint(xv) & 0xffffe000u);
+                const uint4 xf = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xh_, xh_)),
+                                            __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xv - xh_, 0.0f)), 0u, 0u);
                 const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane + opq;
+                floatx16 c2[4] = {splat16(0.0f), splat16(0.0f), splat16(0.0f), splat16(0.0f)};
+                uint4 fh[2][2], fl[2][2];          // [buffer][slab of the tile]: B fragments hi / lo
+                float4 Pq[2], Qq[2];               // P / Q rows of one quad (8 features of this half), double-buffered
+                uint4 af[2][4];                    // W2' fragments of one (slab, output half): ah0, ah1, al0, al1
+                floatx16 g1;                       // geometric term of the tile in production
+                float yy[2], ee[2], uu[2];         // element pair in flight through the three chunks
+
+                auto load_pq = [&](int mt, int qd, int buf) {
+                    Pq[buf] = *reinterpret_cast<const float4*>(Pp + 32 * mt + 8 * qd);
+                    Qq[buf] = *reinterpret_cast<const float4*>(Qp + 32 * mt + 8 * qd);
+                };
+                auto load_a = [&](int slab, int oh, int buf) {
+                    af[buf][0] = Wq[(slab * 4 + 2 * oh) * 64]; af[buf][1] = Wq[(slab * 4 + 2 * oh + 1) * 64];
+                    af[buf][2] = Wq[((8 + slab) * 4 + 2 * oh) * 64]; af[buf][3] = Wq[((8 + slab) * 4 + 2 * oh + 1) * 64];
+                };
+                // the three VALU chunks of element pair e (registers 2e, 2e+1) of the tile in production
+                auto chunk_a = [&](int e) {
+                    const float4 P = Pq[(e >> 1) & 1], Q = Qq[(e >> 1) & 1];
+                    const float p0 = (e & 1) ? P.z + Q.z : P.x + Q.x, p1 = (e & 1) ? P.w + Q.w : P.y + Q.y;
+                    yy[0] = fmaf(g1[2 * e], invS1, p0); yy[1] = fmaf(g1[2 * e + 1], invS1, p1);
+                    ee[0] = __builtin_amdgcn_exp2f(yy[0]); ee[1] = __builtin_amdgcn_exp2f(yy[1]);
+                };
+                auto chunk_b = [&]() {
+                    // SiLU in u-form, scaled into the fp16 range: y * sa / (1 + 2^y)
+                    ee[0] = __builtin_amdgcn_rcpf(fmaf(ee[0], isa, isa)); ee[1] = __builtin_amdgcn_rcpf(fmaf(ee[1], isa, isa));
+                };
+                auto chunk_c = [&](int e, int buf) {
+                    uu[0] = yy[0] * ee[0]; uu[1] = yy[1] * ee[1];
+                    const float h0 = __uint_as_float(__float_as_uint(uu[0]) & 0xffffe000u);
+                    const float h1 = __uint_as_float(__float_as_uint(uu[1]) & 0xffffe000u);
+                    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
+                    const unsigned lp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(uu[0] - h0, uu[1] - h1));
+                    const int sl = e >> 2, d = e & 3;           // slab of the tile, dword of the fragment
+                    if (d == 0) { fh[buf][sl].x = hp; fl[buf][sl].x = lp; }
+                    if (d == 1) { fh[buf][sl].y = hp; fl[buf][sl].y = lp; }
+                    if (d == 2) { fh[buf][sl].z = hp; fl[buf][sl].z = lp; }
+                    if (d == 3) { fh[buf][sl].w = hp; fl[buf][sl].w = lp; }
+                };
+                // MFMA number i (0..23) of the stage that consumes tile k: group = (slab, output half), six per group
+                auto mfma_i = [&](int k, int i) {
+                    const int grp = i / 6, m6 = i % 6, sl = grp >> 1, oh = grp & 1, buf = grp & 1;
+                    const uint4& a = af[buf][(m6 < 2 ? 2 : 0) + (m6 & 1)];          // lo, lo, hi, hi, hi, hi
+                    const uint4& b = (m6 == 2 || m6 == 3) ? fl[k & 1][sl] : fh[k & 1][sl];
+                    c2[2 * oh + (m6 & 1)] = mfma_h(a, b, c2[2 * oh + (m6 & 1)]);
+                };
+
+                // prologue: tile 0 of the first layer (no MFMAs to hide under yet), first W2' group, first rows
+                load_pq(0, 0, 0);
+                g1 = mfma_h(gaf[0], xf, splat16(0.0f));
+                load_a(0, 0, 0);
 #pragma unroll
-                for (int mh = 0; mh < 2; ++mh) {
-                    floatx16 c0 = splat16(0.0f), c1 = splat16(0.0f);
+                for (int e = 0; e < 8; ++e) {
+                    if ((e & 1) == 0 && e < 6) load_pq(0, (e >> 1) + 1, ((e >> 1) + 1) & 1);
+                    chunk_a(e); chunk_b(); chunk_c(e, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        const uint4 ah0 = Wq[(s * 4 + 2 * mh) * 64], ah1 = Wq[(s * 4 + 2 * mh + 1) * 64];
-                        const uint4 al0 = Wq[((8 + s) * 4 + 2 * mh) * 64], al1 = Wq[((8 + s) * 4 + 2 * mh + 1) * 64];
-                        c0 = mfma_h(al0, bh[s], c0); c1 = mfma_h(al1, bh[s], c1);
-                        c0 = mfma_h(ah0, bl[s], c0); c1 = mfma_h(ah1, bl[s], c1);
-                        c0 = mfma_h(ah0, bh[s], c0); c1 = mfma_h(ah1, bh[s], c1);
+                for (int k = 0; k < 4; ++k) {
+                    // stage k: the 24 MFMAs of tile k, tile k+1 of the first layer in their shadow
+                    if (k < 3) { g1 = mfma_h(gaf[k + 1], xf, splat16(0.0f)); load_pq(k + 1, 0, 0); }
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        const int grp = i / 6, m6 = i % 6, e = i / 3, ph = i % 3;
+                        // W2' fragments of the next group (of the next stage after the last group) one group ahead
+                        if (m6 == 0) {
+                            const int ng = grp + 1;
+                            if (ng < 4) load_a(2 * k + (ng >> 1), ng & 1, ng & 1);
+                            else if (k < 3) load_a(2 * (k + 1), 0, 0);
+                        }
+                        mfma_i(k, i);
+                        if (k < 3) {
+                            if (ph == 0) { if ((e & 1) == 0 && e < 6) load_pq(k + 1, (e >> 1) + 1, ((e >> 1) + 1) & 1); chunk_a(e); }
+                            if (ph == 1) chunk_b();
+                            if (ph == 2) chunk_c(e, (k + 1) & 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    epilogue(c0, 2 * mh);
-                    epilogue(c1, 2 * mh + 1);
+                }
+                const float m = float(m_raw);
+                TileVecs tv0 = load_vecs(0);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    keep_vecs(tv0);
+                    TileVecs tv1;
+                    if (mt < 3) tv1 = load_vecs(mt + 1);       // lands under this tile's epilogue
+                    __builtin_amdgcn_sched_barrier(0);
+                    epilogue(c2[mt], mt, tv0, m);
+                    if (mt < 3) tv0 = tv1;
                 }
             }
             if (EQUIV) {
@@ -520,7 +603,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 const float s_all = lo + hi;
                 // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
                 const float den = sqrtf(r + 1e-8f) + norm_constant;
-                const float f = ok ? s_all * m : 0.0f;
+                const float f = ok ? s_all * float(m_raw) : 0.0f;
                 ax += (dx / den) * f; ay += (dy / den) * f; az += (dz / den) * f;
             }
         }
@@ -544,16 +627,16 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 // sum of the slot partials of every atom, chunks in ascending order (deterministic).  GCL: each thread owns up to four
 // (atom, 4-feature) groups and returns them in registers (the destination v.C overlaps the partial buffer); max |agg|.
 struct AggRegs {
-    float4 v[4 * THREADS / DL_DBG_RTHREADS];
+    float4 v[4];
 };
 __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out) {
     const SlotPlan pl = slot_plan(nb);
     float am = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 4 * THREADS / DL_DBG_RTHREADS; ++k) {
-        const int e = tid + DL_DBG_RTHREADS * k;
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + THREADS * k;
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < DL_DBG_RTHREADS && e < nb * 32) {
+        if (e < nb * 32) {
             const float* src = v.A + (e >> 5) * pl.g * PB_STRIDE + 4 * (e & 31);
             for (int ch = 0; ch < pl.g; ++ch) {
                 const float4 p = *reinterpret_cast<const float4*>(src + ch * PB_STRIDE);
@@ -567,9 +650,9 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, 
 }
 __device__ __forceinline__ void pair_store_gcl(const Lds& v, int nb, int tid, const AggRegs& in) {
 #pragma unroll
-    for (int k = 0; k < 4 * THREADS / DL_DBG_RTHREADS; ++k) {
-        const int e = tid + DL_DBG_RTHREADS * k;
-        if (tid < DL_DBG_RTHREADS && e < nb * 32) *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = in.v[k];
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + THREADS * k;
+        if (e < nb * 32) *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = in.v[k];
     }
 }
 // coordinate head: aggx[i][0..2] = sum of the slot triples
@@ -621,7 +704,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     prof_event(pf, w, lane, 12);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
-    pair_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc);     // ends with the partial rows in LDS
+    pair_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, pf);     // ends with the partial rows in LDS
     prof_event(pf, w, lane, 13);
     }
     // ---- back: aggregate completion + node MLP (lane indices re-derived, see lane_ids)
@@ -731,7 +814,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
-    pair_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc);   // ends with the partial triples in LDS
+    pair_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc, pf);   // ends with the partial triples in LDS
     prof_event(pf, w, lane, 33);
     }
     // ---- back: coordinate update (lane indices re-derived, see lane_ids)

@@ -63,22 +63,42 @@ dyn.forward(**args)
 torch.cuda.synchronize()
 lib.dl_set_profile_buffer(None)
 ev = buf.cpu()
-names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: barrier+zero agg', (12, 13): 'gcl: EDGE tiles',
-         (13, 14): 'gcl: barriers+spill+h->lds', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
+names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: barrier', (12, 13): 'gcl: PAIR loop + partials',
+         (13, 14): 'gcl: reduce + h->lds', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
          (16, 10): 'gcl: end barrier', (16, 30): 'gcl: end barrier', (30, 31): 'eq: stage+proj', (31, 32): 'eq: barrier',
-         (32, 33): 'eq: EDGE tiles', (33, 34): 'eq: barriers+spill+x', (34, 10): 'eq: end barrier', (34, 3): 'eq: end barrier',
+         (32, 33): 'eq: PAIR loop + partials', (33, 34): 'eq: reduce + x', (34, 10): 'eq: end barrier', (34, 3): 'eq: end barrier',
          (2, 10): 'h->regs', (3, 4): 'output head'}
+inloop = {(40, 41): 'L1 (geo, SiLU, split)', (41, 42): 'M0 (48 mfma)', (42, 43): 'E0 (epilogue)', (43, 44): 'M1 (48 mfma)',
+          (44, 45): 'E1 (epilogue)'}
 for w in range(8):
     e = ev[w]
     n = int((e[:, 0] != 0).sum())
+    tags = [int(x) for x in e[:n, 0]]
+    ts = [int(x) for x in e[:n, 1]]
+    # pass-level events only (tags < 40), in-loop events (40..45) of step 2 reported separately per pass kind
+    top = [(tg, t_) for tg, t_ in zip(tags, ts) if tg < 40]
     tot = collections.OrderedDict()
+    for k in range(len(top) - 1):
+        nm = names.get((top[k][0], top[k + 1][0]), str((top[k][0], top[k + 1][0])))
+        tot[nm] = tot.get(nm, 0) + top[k + 1][1] - top[k][1]
+    total = top[-1][1] - top[0][1]
+    loop = {'gcl': collections.OrderedDict(), 'eq': collections.OrderedDict()}
+    cnt = {'gcl': 0, 'eq': 0}
+    kind = 'gcl'
     for k in range(n - 1):
-        key = (int(e[k, 0]), int(e[k + 1, 0]))
-        nm = names.get(key, str(key))
-        tot[nm] = tot.get(nm, 0) + int(e[k + 1, 1] - e[k, 1])
-    total = int(e[n - 1, 1] - e[0, 1])
-    print(f'wave {w}: gcl EDGE {tot.get("gcl: EDGE tiles", 0):9d}  eq EDGE {tot.get("eq: EDGE tiles", 0):9d}  total {total}')
-    if w in (0, 3, 7):
+        if tags[k] == 12: kind = 'gcl'
+        if tags[k] == 32: kind = 'eq'
+        key = (tags[k], tags[k + 1])
+        if key in inloop:
+            loop[kind][inloop[key]] = loop[kind].get(inloop[key], 0) + ts[k + 1] - ts[k]
+            if key == (40, 41): cnt[kind] += 1
+    print(f'wave {w}: gcl PAIR {tot.get("gcl: PAIR loop + partials", 0):9d}  eq PAIR {tot.get("eq: PAIR loop + partials", 0):9d}  total {total}')
+    if w in (0, 4, 7):
         print(f'--- wave {w}: {n} events, total {total} ticks')
         for nm, v in tot.items():
             print(f'   {nm:32s} {v:10d}  {100.0 * v / total:5.1f}%')
+        for kind in ('gcl', 'eq'):
+            if cnt[kind]:
+                print(f'   in-loop, step 2 of {cnt[kind]} {kind} passes (ticks per step): ' +
+                      ', '.join(f'{nm} {v // cnt[kind]}' for nm, v in loop[kind].items()) +
+                      f' | sum {sum(loop[kind].values()) // cnt[kind]}')
