@@ -26,7 +26,9 @@ DATA_ATTRS_TO_ADD_LAST_DIM = {
 }
 
 # linker-size histogram of the ZINC train split (const.py:50-61)
-LINKER_SIZE_DIST = {3: 113928, 4: 85540, 5: 77671, 6: 70946, 7: 30408, 8: 12712, 9: 5177, 10: 1214, 11: 158, 12: 7}
+# (insertion order as in the reference: DistributionNodes enumerates the dict, so the order decides which size a
+# seeded Categorical draw maps to)
+LINKER_SIZE_DIST = {4: 85540, 3: 113928, 6: 70946, 7: 30408, 5: 77671, 9: 5177, 10: 1214, 8: 12712, 11: 158, 12: 7}
 
 # class tables of the size predictor (const.py:181-206)
 ZINC_TRAIN_LINKER_ID2SIZE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 12]

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import const
-from .datasets import collate_with_fragment_edges, collate_with_fragment_without_pocket_edges
+from .datasets import MOADDataset, collate_with_fragment_edges, collate_with_fragment_without_pocket_edges
 from .io import get_pocket, parse_molecule, pocket_arrays, read_molecule, read_pocket, save_xyz_file
 from .lightning import DDPM
 from .linker_size import SizeClassifier
@@ -143,6 +143,8 @@ def _generate_pocket_common(frag, pocket, ddpm, sample_fn, output_dir, name, n_s
         'fragment_mask': t(np.concatenate([ones_f, ones_p])), 'linker_mask': t(np.concatenate([zeros_f, zeros_p])),
         'num_atoms': len(positions),
     }] * n_samples
+    dataset = MOADDataset(data=dataset)                   # generate_with_pocket.py:249-250: DDPM.sample_chain keys the
+    ddpm.val_dataset = dataset                            # centre-of-mass mask on the dataset type (lightning.py:443)
     return _sample_and_save(ddpm, dataset, collate_with_fragment_without_pocket_edges, sample_fn,
                             min(n_samples, max_batch_size), output_dir, name, com_key='fragment_only_mask',
                             hide_pocket=True)

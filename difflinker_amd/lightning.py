@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import utils
-from .datasets import create_templates_for_linker_generation
+from .datasets import MOADDataset, create_templates_for_linker_generation
 from .edm import EDM, InpaintingEDM
 from .egnn import Dynamics, DynamicsWithPockets
 
@@ -75,9 +75,6 @@ class DDPM(_Base):
             graph_type = '4A' if self.pockets else 'FC'
         if type(activation) is str:
             activation = get_activation(activation)
-        if inpainting and self.pockets:
-            raise NotImplementedError('inpainting with pocket-conditioned dynamics')
-
         dynamics_class = DynamicsWithPockets if self.pockets else Dynamics
         dynamics = dynamics_class(
             in_node_nf=in_node_nf, n_dims=n_dims, context_node_nf=context_node_nf, device=torch_device,
@@ -92,6 +89,9 @@ class DDPM(_Base):
             noise_schedule=diffusion_noise_schedule, noise_precision=diffusion_noise_precision,
             loss_type=diffusion_loss_type, norm_values=normalize_factors,
         )
+        from .const import LINKER_SIZE_DIST
+        from .linker_size import DistributionNodes
+        self.linker_size_sampler = DistributionNodes(LINKER_SIZE_DIST)          # lightning.py:113
 
     # ---- checkpoints ----------------------------------------------------------------------------------
     @classmethod
@@ -174,7 +174,7 @@ class DDPM(_Base):
 
         if self.inpainting:
             center_of_mass_mask = node_mask
-        elif self.pockets and self.center_of_mass == 'fragments':
+        elif isinstance(self.val_dataset, MOADDataset) and self.center_of_mass == 'fragments':     # lightning.py:443
             center_of_mass_mask = template_data['fragment_only_mask']
         elif self.center_of_mass == 'fragments':
             center_of_mass_mask = fragment_mask

@@ -105,3 +105,64 @@ def seeded_size_state_dict(in_nf, hidden_nf, out_nf, n_layers, seed, batch_norm=
             val = np.asarray(7, dtype=np.int64)
         sd[prefix + key] = torch.from_numpy(np.asarray(val))
     return sd
+
+
+# ---- inputs shared by tests/golden/make_golden.py (which runs the reference on them) and the tests ----------------
+def ragged_fc_molecules(sizes, linkers, nf, seed):
+    """Per-molecule dicts of a ragged fully-connected batch: fragments first, the linker atoms last."""
+    g = torch.Generator().manual_seed(seed)
+    mols = []
+    for n, nl in zip(sizes, linkers):
+        frag = torch.zeros(n)
+        frag[:n - nl] = 1
+        types = torch.randint(0, nf, (n,), generator=g)
+        mols.append({'positions': 2.0 * torch.randn((n, 3), generator=g),
+                     'one_hot': torch.nn.functional.one_hot(types, nf).float(),
+                     'anchors': torch.zeros(n), 'fragment_mask': frag, 'linker_mask': 1 - frag,
+                     'num_atoms': n, 'uuid': 0, 'name': 'm'})
+    return mols
+
+
+GLUE_HPARAMS = dict(in_node_nf=8, n_dims=3, context_node_nf=1, hidden_nf=128, activation='silu', tanh=False, n_layers=1,
+                    attention=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+                    aggregation_method='sum', diffusion_steps=500, diffusion_noise_schedule='polynomial_2',
+                    diffusion_noise_precision=1e-5, diffusion_loss_type='l2', normalize_factors=[1, 4, 10],
+                    include_charges=False, model='egnn_dynamics', data_path='d', train_data_prefix='zinc_final_train',
+                    val_data_prefix='zinc_final_val', batch_size=8, lr=2e-4, torch_device='cpu', test_epochs=20,
+                    n_stability_samples=10, normalization='batch_norm', anchors_context=False)
+
+
+def glue_cases():
+    """(tag, hparam overrides, pockets, linker sizes asked of ``sample_fn``) of the ``ddpm_glue`` fixture."""
+    return [
+        ('fc', {}, False, [4, 2, 6]),
+        ('fc_anchors', dict(anchors_context=True, context_node_nf=2, center_of_mass='anchors'), False, [3, 5, 2]),
+        ('pocket', dict(train_data_prefix='MOAD_train.full', val_data_prefix='MOAD_val.full', context_node_nf=2,
+                        graph_type='FC-10A-4A', in_node_nf=9), True, [3, 4]),
+        ('pocket_anchors', dict(train_data_prefix='MOAD_train.full', val_data_prefix='MOAD_val.full', context_node_nf=3,
+                                anchors_context=True, in_node_nf=9), True, [2, 5]),
+    ]
+
+
+def glue_molecules(pockets, nf, seed):
+    """Per-molecule dicts as the reference's datasets / generation scripts build them (datasets.py:56-100,
+    generate_with_pocket.py:233-248): fragments first, then (pockets) the pocket atoms, then the linker."""
+    g = torch.Generator().manual_seed(seed)
+    mols = []
+    for n_frag, n_pocket, n_link in ([(9, 14, 4), (7, 11, 3)] if pockets else [(9, 0, 4), (6, 0, 2), (11, 0, 5)]):
+        n = n_frag + n_pocket + n_link
+        types = torch.randint(0, nf, (n,), generator=g)
+        role = torch.cat([torch.zeros(n_frag), torch.ones(n_pocket), 2 * torch.ones(n_link)])
+        anchors = torch.zeros(n)
+        anchors[0] = 1
+        anchors[n_frag - 1] = 1
+        m = {'uuid': len(mols), 'name': f'm{len(mols)}', 'positions': 2.5 * torch.randn((n, 3), generator=g),
+             'one_hot': torch.nn.functional.one_hot(types, nf).float(), 'anchors': anchors,
+             'fragment_mask': (role < 2).float(), 'linker_mask': (role == 2).float(), 'num_atoms': n}
+        if pockets:
+            m['fragment_only_mask'] = (role == 0).float()
+            m['pocket_mask'] = (role == 1).float()
+        mols.append(m)
+    return mols
+
+

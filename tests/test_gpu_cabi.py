@@ -43,6 +43,12 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
         ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
                                            t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
         assert rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= 2e-5 and flags.cpu().tolist() == [0, 0, 0]
+        # the velocity too: vel = x_final - x is a difference of fp32 coordinates, so both sides carry a few ulp(|x|) of
+        # absolute error in it; that floor is removed before normalising (as tests/test_gpu_parity.report does)
+        dv = float((out.cpu()[..., :3].double() - ref[..., :3].double()).norm())
+        floor = 4 * 2.0 ** -24 * float(z[..., :3].double().norm())
+        assert max(0.0, dv - floor) / float(ref[..., :3].double().norm()) <= 2e-5
+        assert float(out.cpu()[..., :3].abs().max()) > 0
         # status codes: null pointer, negative batch, a molecule with more atoms than dl_max_atoms() (flag bit 2)
         assert lib.dl_egnn_forward_fc(model, B, N, None, p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == -1
         assert lib.dl_egnn_forward_fc(model, -1, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == -1
