@@ -47,6 +47,9 @@ def parse():
                     help="'torch': the reference's torch.randn stream (default); 'philox': draws generated inside the kernel")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-forwards', type=int, default=2)
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the secondary measurements (exact-fp32 mode, C4 pockets, other batch sizes) of the N=1 line')
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'fp32'], help='arithmetic mode (default: f16x3)')
     return ap.parse_args()
 
 
@@ -59,6 +62,8 @@ def build_model(cfg, device):
     edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2',
               noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
     edm.T = cfg['T']
+    if cfg.get('precision'):
+        dyn.precision = cfg['precision']
     return edm.to(device)
 
 
@@ -118,6 +123,65 @@ def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
             's_per_forward_full_batch': fwd_full}
 
 
+def time_chains(edm, inp, steps=1, warmup=1):
+    """(seconds per chain, kernel ms or None) of ``edm.sample_chain`` on resident inputs."""
+    edm.profile_events = True
+    for _ in range(warmup):
+        edm.sample_chain(keep_frames=1, **inp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(steps):
+        edm.sample_chain(keep_frames=1, **inp)
+        ev = getattr(edm, 'last_kernel_events', None)
+        kms.append(ev)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    k = None
+    if kms and kms[0] is not None:
+        k = sum(s.elapsed_time(e) for s, e in kms) / len(kms)
+    return dt, k
+
+
+def secondary_measurements(device, a):
+    """Driver-timed companions of the headline: the exact-fp32 arithmetic mode on the same C2 batch, the
+    pocket configuration C4, and C2 at batch sizes off the one-molecule-per-compute-unit sweet spot.  One warm-up chain
+    and one timed chain each (a chain is 501 forwards: the timing noise is well below 1 %)."""
+    from difflinker_amd import synthetic
+    out = []
+
+    def run(tag, config, batch, precision, note):
+        data, cfg = synthetic.make_batch(config, seed=1000, batch=batch)
+        cfg['precision'] = precision
+        pockets = cfg['graph_type'] != 'FC'
+        inp_cpu = synthetic.sampler_inputs(data, pockets=pockets)
+        inp = {k: v.to(device) for k, v in inp_cpu.items()}
+        edm = build_model(cfg, device)
+        edm.noise_source = a.noise
+        if hasattr(edm, 'last_kernel_events'):
+            del edm.last_kernel_events
+        torch.manual_seed(4321)
+        dt, kms = time_chains(edm, inp)
+        pairs, nodes = synthetic.pair_and_node_counts(data)
+        if pockets:
+            pairs = pocket_edge_count(inp_cpu)
+        flops = synthetic.flops_min(128, cfg['n_layers'], cfg['nf'] + cfg['ctx'] + 1, pairs, nodes) * (cfg['T'] + 1)
+        peak = FP32_MFMA_PEAK_TFLOPS if precision == 'fp32' else F16_MFMA_PEAK_TFLOPS / 3.0
+        t_k = (kms * 1e-3) if kms is not None else dt
+        B = inp['x'].shape[0]
+        out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}; {note}',
+                    'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
+                    'roofline_frac': flops / t_k / 1e12 / peak, 'roofline_peak_tflops': peak,
+                    'achieved_tflops': flops / t_k / 1e12})
+
+    run('c2_fp32_mode', 'C2', None, 'fp32', 'exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), same batch as the headline')
+    run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph rebuilt every forward')
+    for b in (64, 257, 512):
+        run(f'c2_batch_{b}', 'C2', b, 'f16x3', 'one molecule occupies one of the 256 compute units for the whole chain; '
+            'workgroups launched biggest molecule first')
+    return out
+
+
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -139,29 +203,36 @@ def main():
     if rank != 0:
         entry.build()
     from difflinker_amd import synthetic
-    from difflinker_amd.distributed import all_gather_frames
 
-    data, cfg = synthetic.make_batch(a.config, seed=1000 + rank, batch=a.batch, uniform_size=a.uniform_size)
+    from difflinker_amd.distributed import sample_chain_sharded, shard_bounds
+    # weak scaling: the logical batch has 256 molecules per GPU (config C3 at N = 8); every rank builds the same logical
+    # batch from one seed and samples its contiguous shard (distributed.sample_chain_sharded), so the N-GPU job computes
+    # exactly what one GPU would for that batch (in-kernel counter-based noise keyed by the GLOBAL molecule index)
+    per_gpu = a.batch if a.batch is not None else synthetic.CONFIGS[a.config]['batch']
+    data, cfg = synthetic.make_batch(a.config, seed=1000, batch=per_gpu * world, uniform_size=a.uniform_size)
     if a.T is not None:
         cfg['T'] = a.T
+    cfg['precision'] = a.precision
     pockets = cfg['graph_type'] != 'FC'
     inp_cpu = synthetic.sampler_inputs(data, pockets=pockets)
     inp = {k: v.to(device) for k, v in inp_cpu.items()}    # inputs resident in HBM before the timed region
-    B, N = inp['x'].shape[:2]
+    Bg, N = inp['x'].shape[:2]
+    lo, hi = shard_bounds(Bg, rank, world)
+    B = hi - lo
     edm = build_model(cfg, device)
-    edm.noise_source = a.noise
+    edm.noise_source = a.noise if world == 1 else 'philox'
     edm.profile_events = True
-    pairs, nodes = synthetic.pair_and_node_counts(data)
+    shard_cpu = {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == Bg else v) for k, v in inp_cpu.items()}
+    pairs, nodes = synthetic.pair_and_node_counts({'atom_mask': data['atom_mask'][lo:hi]})
     if pockets:
-        pairs = pocket_edge_count(inp_cpu)
+        pairs = pocket_edge_count(shard_cpu)
     fin = cfg['nf'] + cfg['ctx'] + 1
     flops_fwd = synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes)
 
     def one_chain():
-        chain = edm.sample_chain(keep_frames=1, **inp)
-        if world > 1:
-            chain = all_gather_frames(chain, B * world)    # only the final frame crosses GPUs
-        return chain
+        if world == 1:
+            return edm.sample_chain(keep_frames=1, **inp)
+        return sample_chain_sharded(edm, inp, keep_frames=1)      # one all-gather of the final frame (RCCL)
 
     torch.manual_seed(1234 + rank)
     for _ in range(a.warmup):
@@ -201,19 +272,20 @@ def main():
                 'VALU (2 SiLU per pair and channel + fp16 splits) + matrix time, see DESIGN.md'
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
-        # fabric-side bytes per launch from the committed rocprofv3 --pmc passes of this kernel (profiles/, collected at
-        # T=20 = 21 forwards by scripts/profile_gpu.sh; FETCH_SIZE already doubled for gfx950), scaled to this launch
+        # fabric-side bytes per launch: NOT measured in this run (rocprofv3 --pmc passes cannot run inside the timed
+        # process) but taken from the committed counter passes of the same launch (profiles/r02/pmc_chain_kernel_T500.json,
+        # collected by scripts/profile_gpu.sh on this command line; FETCH_SIZE doubled for gfx950) - labelled as such
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_final', 'pmc_chain_kernel_T20.json')
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02', 'pmc_chain_kernel_T500.json')
         if not pockets and precision == 'f16x3' and a.config == 'C2' and not a.uniform_size and os.path.exists(pmc_path):
             d_ = json.load(open(pmc_path))['_derived']
-            per_fwd = (d_['hbm_fetch_bytes_per_launch_x2_corrected'] + d_['hbm_write_bytes_per_launch']) / 21.0
+            per_fwd = (d_['hbm_fetch_bytes_per_launch_x2_corrected'] + d_['hbm_write_bytes_per_launch']) / float(d_['forwards_per_launch'])
             traffic = per_fwd * (cfg['T'] + 1) * (B / 256.0)
-            traffic_note = 'FETCH_SIZE x2 + WRITE_SIZE of profiles/r01_final/pmc_chain_kernel_T20.json (T=20 launch) scaled by ' \
-                           'forwards; fabric-side, Infinity-Cache hits included (spill scratch + weight streaming); ' \
-                           'algorithmic HBM bytes are ~2 MB per forward'
+            traffic_note = 'from_profile: FETCH_SIZE x2 + WRITE_SIZE of profiles/r02/pmc_chain_kernel_T500.json (the same launch, ' \
+                           'separate rocprofv3 --pmc passes); fabric-side, Infinity-Cache hits included (scratch + weight ' \
+                           'streaming); algorithmic HBM bytes are ~2 MB per forward'
         out = {
-            'metric': 'molecules/sec (500-step sample_chain)', 'value': B * world * a.steps / elapsed,
+            'metric': 'molecules/sec (500-step sample_chain)', 'value': Bg * a.steps / elapsed,
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic', 'noise': a.noise,
@@ -222,7 +294,7 @@ def main():
                                    f'(n_b {"= N" if a.uniform_size else ("~ U{35..50}" if not pockets else "30 fragment + 250 pocket + 6..12 linker atoms")}), T={cfg["T"]} reverse steps '
                                    f'+ decode = {cfg["T"] + 1} EGNN forwards per step; random-init weights, synthetic '
                                    f'fragment graphs',
-                       'global_batch': B * world, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}',
+                       'global_batch': Bg, 'molecules_per_gpu': B, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}' + ('' if world == 1 else ' (distributed.sample_chain_sharded: contiguous shards, in-kernel Philox noise keyed by the global molecule index, one RCCL all-gather of the final frame)'),
                        'real_pairs_per_forward': pairs, 'real_atoms': nodes},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
@@ -234,6 +306,8 @@ def main():
                           'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '
                                   'LDS-resident for the whole chain, so the HBM fraction is << 1 % by design'},
         }
+        if world == 1 and not a.no_secondary and a.config == 'C2' and not a.uniform_size and a.batch is None and a.T is None:
+            out['secondary'] = secondary_measurements(device, a)
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(edm, cfg, inp_cpu, a.cpu_forwards)
         print(json.dumps(out))

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIFFLINKER_HIP_LIB') or os.path.join(_HERE, 'libdifflinker_hip.so')
 
 DL_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 PRECISIONS = {'fp32': 0, 'f16x3': 1}
 DL_ERR_TOO_MANY_ATOMS = -3
 
@@ -25,6 +25,8 @@ class DLConfig(ctypes.Structure):
         ('hidden_nf', ctypes.c_int32), ('n_layers', ctypes.c_int32), ('inv_sublayers', ctypes.c_int32),
         ('condition_time', ctypes.c_int32), ('norm_constant', ctypes.c_float),
         ('normalization_factor', ctypes.c_float), ('precision', ctypes.c_int32),
+        ('attention', ctypes.c_int32), ('tanh', ctypes.c_int32), ('coords_range', ctypes.c_float),
+        ('aggregation_mean', ctypes.c_int32), ('sin_embedding', ctypes.c_int32),
     ]
 
 
@@ -56,6 +58,7 @@ class DLChainArgs(ctypes.Structure):
         ('inv_alpha0', ctypes.c_float), ('sigma0', ctypes.c_float), ('sigma_x', ctypes.c_float),
         ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float),
         ('chain', ctypes.c_void_p), ('nan_flags', ctypes.c_void_p), ('nan_step', ctypes.c_void_p),
+        ('order', ctypes.c_void_p),
     ]
 
 

@@ -179,12 +179,15 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // the fourth slot then receives the next packed vector, unused).  Grid waves only; issued as soon as the previous
 // pair loop has released v.W / v.vec, so the image lands under the node phases.
 __device__ __forceinline__ void stage_dma(const Lds& v, const float* __restrict__ wimg, const float* __restrict__ vecs,
-                                          int w, int tid) {
+                                          const float* __restrict__ vec4, int w, int tid) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    if (w < 4 * HID / 256)                // wave-uniform; first, so that no wait the compiler adds covers the image
-        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const float4*>(vecs) + tid), (lptr_t)(v.vec + 256 * w),
-                                         16, 0, 0);
+    if (w < 4 * HID / 256) {              // wave-uniform; first, so that no wait the compiler adds covers the image
+        // lanes 0..95: wr', wd', b2'|b6' (contiguous at `vecs`); lanes 96..127: the fourth vector (w7' / w_att') at `vec4`
+        const float4* src = (tid < 96) ? reinterpret_cast<const float4*>(vecs) + tid
+                                       : reinterpret_cast<const float4*>(vec4) + (tid - 96);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(v.vec + 256 * w), 16, 0, 0);
+    }
     const float4* src = reinterpret_cast<const float4*>(wimg);
 #pragma unroll
     for (int it = 0; it < UNIT / 4 / GTHREADS; ++it)
@@ -243,7 +246,8 @@ __device__ __forceinline__ void load_next(PreW& pw, const NextPass& nx, int w, i
 }
 __device__ __forceinline__ void stage_next(const Lds& v, const NextPass& nx, int w, int tid) {
     if (nx.base == nullptr) return;
-    stage_dma(v, nx.base + (nx.equiv ? E_W6T : G_W2T), nx.base + (nx.equiv ? E_VEC : G_VEC) + HID, w, tid);
+    stage_dma(v, nx.base + (nx.equiv ? E_W6T : G_W2T), nx.base + (nx.equiv ? E_VEC : G_VEC) + HID,
+              nx.base + (nx.equiv ? E_VEC + 4 * HID : G_VEC + 6 * HID), w, tid);
 }
 
 // store one accumulator element of tile row `row` to a [n][LDH] buffer; rows >= n_b go to the sink row
@@ -325,10 +329,12 @@ __device__ __forceinline__ void split8t(const float (&u)[8], uint4& hi, uint4& l
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <bool EQUIV, int PREC>
+// ATT (GCL only): edge attention m_ij *= sigmoid(w_att . m_ij + b_att) (egnn.py:52-54); `head` = b_att.
+// EQUIV: `head` = coords_range when the coordinate head goes through tanh (egnn.py:104-105), 0 otherwise.
+template <bool EQUIV, int PREC, bool ATT>
 __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask, int N,
                                            float norm_constant, float sa, float inv_scale, const float* __restrict__ sc,
-                                           Prof& pf) {
+                                           float head, Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
     const SlotPlan pl = slot_plan(nb);
     const int q = pl.q;
@@ -416,7 +422,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     tv.b[qq] = *reinterpret_cast<const float4*>(bias_p + 32 * mt + 8 * qq);
-                    if (EQUIV) tv.w[qq] = *reinterpret_cast<const float4*>(w7_p + 32 * mt + 8 * qq);
+                    if (EQUIV || ATT) tv.w[qq] = *reinterpret_cast<const float4*>(w7_p + 32 * mt + 8 * qq);
                 }
                 return tv;
             };
@@ -426,25 +432,38 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     asm volatile("" : "+v"(tv.b[qq].x), "+v"(tv.b[qq].y), "+v"(tv.b[qq].z), "+v"(tv.b[qq].w));
-                    if (EQUIV) asm volatile("" : "+v"(tv.w[qq].x), "+v"(tv.w[qq].y), "+v"(tv.w[qq].z), "+v"(tv.w[qq].w));
+                    if (EQUIV || ATT) asm volatile("" : "+v"(tv.w[qq].x), "+v"(tv.w[qq].y), "+v"(tv.w[qq].z), "+v"(tv.w[qq].w));
                 }
             };
             // SiLU + mask + sum over senders (GCL) / w7' dot (coordinate head) of one 32-feature tile of D2
-            auto epilogue = [&](const floatx16& c2, int mt, const TileVecs& tv, float m) {
+            auto epilogue = [&](floatx16& c2, int mt, const TileVecs& tv, float m) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const float bb[4] = {tv.b[qq].x, tv.b[qq].y, tv.b[qq].z, tv.b[qq].w};
                     float ww[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (EQUIV) { ww[0] = tv.w[qq].x; ww[1] = tv.w[qq].y; ww[2] = tv.w[qq].z; ww[3] = tv.w[qq].w; }
+                    if (EQUIV || ATT) { ww[0] = tv.w[qq].x; ww[1] = tv.w[qq].y; ww[2] = tv.w[qq].z; ww[3] = tv.w[qq].w; }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int reg = 4 * qq + k;
                         const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
                         const float u2 = silu_u(y2);
-                        if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
-                        else ssum = fmaf(ww[k], u2, ssum);
+                        if (EQUIV || ATT) ssum = fmaf(ww[k], u2, ssum);
+                        if (ATT) c2[reg] = u2;                       // the message waits for its attention weight
+                        else if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
                     }
                 }
+            };
+            // attention: one logit per pair over all 128 features (the other lane half holds the other 64), then the masked,
+            // weighted message joins the receiver's sums
+            auto attend = [&](floatx16 (&c2)[4], float m) {
+                float lo, hi;
+                both_halves(ssum, lo, hi);
+                const float logit = (lo + hi) + head;
+                const float mw = m * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * logit));
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) agg[mt][reg] = fmaf(mw, c2[mt][reg], agg[mt][reg]);
             };
 
             if constexpr (PREC == 0) {
@@ -493,6 +512,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     TileVecs tv = load_vecs(mt);
                     epilogue(c2[mt], mt, tv, m);
                 }
+                if (ATT) attend(c2, m);
             } else {
                 // ---- f16x3, software-pipelined IN the wave.  A wave issues at most one VALU instruction every ~4.6 cycles and
                 // is blocked at an MFMA while the matrix pipe is busy, so a phase-separated stream (all SiLUs, then all MFMAs)
@@ -595,12 +615,15 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     epilogue(c2[mt], mt, tv0, m);
                     if (mt < 3) tv0 = tv1;
                 }
+                if (ATT) attend(c2, m);
             }
             if (EQUIV) {
                 // s = w7'.u2 over all 128 features: this lane summed its half's 64, the other half holds the rest
                 float lo, hi;
                 both_halves(ssum, lo, hi);
-                const float s_all = lo + hi;
+                float s_all = lo + hi;
+                if (head != 0.0f)                                   // tanh(s) * coords_range (egnn.py:104-105); wave-uniform
+                    s_all = head * (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * s_all)));
                 // coord_diff = (x_i - x_j) / (sqrt(r + 1e-8) + norm_constant)   (egnn.py:299-300)
                 const float den = sqrtf(r + 1e-8f) + norm_constant;
                 const float f = ok ? s_all * float(m_raw) : 0.0f;
@@ -629,7 +652,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 struct AggRegs {
     float4 v[4];
 };
-__device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out) {
+__device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out, float scale) {
     const SlotPlan pl = slot_plan(nb);
     float am = 0.0f;
 #pragma unroll
@@ -642,6 +665,7 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, 
                 const float4 p = *reinterpret_cast<const float4*>(src + ch * PB_STRIDE);
                 s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
             }
+            s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;      // 1, or 1/N for aggregation_method='mean'
             am = fmaxf(fmaxf(am, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
         }
         out.v[k] = s;
@@ -656,7 +680,7 @@ __device__ __forceinline__ void pair_store_gcl(const Lds& v, int nb, int tid, co
     }
 }
 // coordinate head: aggx[i][0..2] = sum of the slot triples
-__device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid) {
+__device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid, float scale) {
     const SlotPlan pl = slot_plan(nb);
     if (tid < nb) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -664,7 +688,7 @@ __device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid)
             const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (tid * pl.g + ch));
             sx += p.x; sy += p.y; sz += p.z;
         }
-        v.aggx[4 * tid + 0] = sx; v.aggx[4 * tid + 1] = sy; v.aggx[4 * tid + 2] = sz;
+        v.aggx[4 * tid + 0] = sx * scale; v.aggx[4 * tid + 1] = sy * scale; v.aggx[4 * tid + 2] = sz * scale;
     }
 }
 
@@ -682,7 +706,7 @@ __device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restr
 template <int PREC>
 __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __restrict__ g,
                                          floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf, int& par,
-                                         PreW& pw, const NextPass nx) {
+                                         PreW& pw, const NextPass nx, const ModelDims& md) {
     const float* vecs = g + G_VEC;
     const float* sc = g + G_SCALE;
     float s_h;
@@ -704,7 +728,9 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     prof_event(pf, w, lane, 12);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
-    pair_phase<false, PREC>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, pf);     // ends with the partial rows in LDS
+    // ends with the partial rows in LDS
+    if (md.attention) pair_phase<false, PREC, true>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, sc[8], pf);
+    else pair_phase<false, PREC, false>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
     prof_event(pf, w, lane, 13);
     }
     // ---- back: aggregate completion + node MLP (lane indices re-derived, see lane_ids)
@@ -714,7 +740,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     lds_barrier();                         // partial rows complete
     {
         AggRegs ar;
-        const float am = pair_reduce_gcl(v, nb, tid, ar);
+        const float am = pair_reduce_gcl(v, nb, tid, ar, md.mean ? 1.0f / float(N) : 1.0f);
         lds_barrier();                     // every partial read: P, Q, H, W2' regions are free
         stage_next(v, nx, w, tid);         // next pass's W2' image: DMA under the node phases
         if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
@@ -795,7 +821,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
 template <int PREC>
 __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __restrict__ e,
                                            const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf,
-                                           int par, PreW& pw, const NextPass nx) {
+                                           int par, PreW& pw, const NextPass nx, const ModelDims& md) {
     const float* vecs = e + E_VEC;
     const float* sc = e + E_SCALE;
     {   // ---- front: projections + pair loop
@@ -814,7 +840,8 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
-    pair_phase<true, PREC>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc, pf);   // ends with the partial triples in LDS
+    pair_phase<true, PREC, false>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
+                                  md.tanh ? md.coords_range : 0.0f, pf);      // ends with the partial triples in LDS
     prof_event(pf, w, lane, 33);
     }
     // ---- back: coordinate update (lane indices re-derived, see lane_ids)
@@ -822,7 +849,8 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     const int tid = q.tid, w = q.w, lane = q.lane;
     load_next(pw, nx, w, lane);            // next block's first pass, under the reduction
     lds_barrier();                         // partial triples complete
-    pair_reduce_equiv(v, nb, tid);
+    // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
+    pair_reduce_equiv(v, nb, tid, md.mean ? 1.0f / float(N) : (md.tanh ? md.inv_norm : 1.0f));
     lds_barrier();                         // partials read: P, Q, W2' regions are free
     stage_next(v, nx, w, tid);
     if (PREC == 1 && tid == 0) { v.fmax[FM_PQ] = 0u; v.fmax[FM_X2] = 0u; }
@@ -925,10 +953,10 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
 #pragma nounroll
         for (int gi = 0; gi < 2; ++gi) {
             const NextPass nx = {base + (gi + 1) * GCL_SIZE, gi == 1};
-            gcl_pass<PREC>(v, nb, base + gi * GCL_SIZE, hown, emask, N, pf, par, pw, nx);
+            gcl_pass<PREC>(v, nb, base + gi * GCL_SIZE, hown, emask, N, pf, par, pw, nx, md);
         }
         const NextPass nx = {blk + 1 < md.n_layers ? base + BLOCK_SIZE : nullptr, false};
-        equiv_pass<PREC>(v, nb, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par, pw, nx);
+        equiv_pass<PREC>(v, nb, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par, pw, nx, md);
     }
     prof_event(pf, w, lane, 3);
 
@@ -1059,7 +1087,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     const Lds v = lds_view(lds_raw);
     const dl_chain_args& g = p.a;
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    const int b = g.order ? g.order[blockIdx.x] : int(blockIdx.x);
     const int N = g.N, nf = p.md.nf, D = 3 + nf, T = g.T, K = g.keep_frames, B = g.B;
     const int8_t* nm = g.node_mask + size_t(b) * N;
     const size_t frame = size_t(B) * N * D;
@@ -1102,7 +1130,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         if (decode) { cf.t = 0.0f; cf.alpha_ts = 1.0f; cf.c_eps = 0.0f; cf.sigma = 0.0f; }
         else cf = g.coefs[q];
         Prof pf;
-        pf.buf = (b == 0 && q == 0) ? p.prof : nullptr;
+        pf.buf = (blockIdx.x == 0 && q == 0) ? p.prof : nullptr;
         pf.n = 0;
         forward_molecule<PREC>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf);
         if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
@@ -1342,12 +1370,15 @@ static int32_t check_cfg(const dl_config* c) {
     if (c->n_layers < 1 || c->n_layers > 64) return DL_ERR_UNSUPPORTED;
     if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
     if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_F16X3) return DL_ERR_UNSUPPORTED;
+    if ((c->attention | 1) != 1 || (c->tanh | 1) != 1 || (c->aggregation_mean | 1) != 1) return DL_ERR_BAD_ARG;
+    if (c->sin_embedding != 0) return DL_ERR_UNSUPPORTED;
+    if (c->tanh && !(c->coords_range > 0.0f)) return DL_ERR_BAD_ARG;
     return DL_OK;
 }
 
 int32_t dl_model_num_tensors(const dl_config* cfg) {
     if (!cfg) return DL_ERR_BAD_ARG;
-    return 4 + cfg->n_layers * (2 * 8 + 5);
+    return 4 + cfg->n_layers * (2 * (8 + (cfg->attention ? 2 : 0)) + 5);
 }
 
 int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_tensors, dl_model** out) {
@@ -1397,12 +1428,16 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             const float* w2 = w[ti++]; const float* b2 = w[ti++];     // edge_mlp.2 [128][128]
             const float* w3 = w[ti++]; const float* b3 = w[ti++];     // node_mlp.0 [128][256]
             const float* w4 = w[ti++]; const float* b4 = w[ti++];     // node_mlp.2 [128][128]
+            const float* watt = nullptr; const float* batt = nullptr;
+            if (cfg->attention) { watt = w[ti++]; batt = w[ti++]; }   // att_mlp.0 [1][128], [1]
             const int ld1 = 2 * HID + 2;
             float* sc = g + G_SCALE;
             sc[0] = unit(g + G_W1A, w1, ld1, 0, c);
             sc[1] = unit(g + G_W1B, w1, ld1, HID, c);
             sc[2] = unit(g + G_W3A, w3, 2 * HID, 0, c);
-            sc[3] = unit(g + G_W3B, w3, 2 * HID, HID, inv_norm);      // agg arrives as c*norm*true agg
+            // agg arrives as c * true message sum: the 1/normalization_factor of 'sum' is folded here, the 1/N of 'mean'
+            // is applied where the slot partials are added (N is a property of the batch, not of the model)
+            sc[3] = unit(g + G_W3B, w3, 2 * HID, HID, cfg->aggregation_mean ? 1.0 : inv_norm);
             sc[4] = unit(g + G_W4, w4, HID, 0, 1.0 / c);
             sc[5] = image(g + G_W2, w2, HID, 1.0);
             image_t(g + G_W2T, w2, HID, 1.0);
@@ -1413,6 +1448,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             pack_vec(vv + 3 * HID, b2, 1, c);
             pack_vec(vv + 4 * HID, b3, 1, c);
             pack_vec(vv + 5 * HID, b4, 1, 1.0);
+            if (watt) { pack_vec(vv + 6 * HID, watt, 1, 1.0 / c); sc[8] = batt[0]; }    // logit = w_att . (u2 / c) + b_att
             sc[6] = vec_absmax(vv + 1 * HID);
             sc[7] = vec_absmax(vv + 2 * HID);
         }
@@ -1431,7 +1467,8 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
         pack_vec(vv + 2 * HID, w5 + 2 * HID + 1, ld5, c);
         pack_vec(vv + 3 * HID, b6, 1, c);
-        pack_vec(vv + 4 * HID, w7, 1, inv_norm / c);
+        // s = w7 . SiLU(..): with tanh or the mean the head's raw output is needed, the normalisation follows at run time
+        pack_vec(vv + 4 * HID, w7, 1, (cfg->tanh || cfg->aggregation_mean) ? 1.0 / c : inv_norm / c);
         sc[6] = vec_absmax(vv + 1 * HID);
         sc[7] = vec_absmax(vv + 2 * HID);
     }

@@ -748,6 +748,7 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
         return DL_ERR_BAD_ARG;
     if (B < 0 || N < 1 || graph_type < 0 || graph_type > 2) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf < 2) return DL_ERR_BAD_ARG;                      // needs the fragment/pocket channels
+    if (m->cfg.attention || m->cfg.tanh || m->cfg.aggregation_mean) return DL_ERR_UNSUPPORTED;   // optional hparams: FC kernels only
     return run_sparse(m, B, N, graph_type, xh, t, t_is_scalar, node_mask, linker_mask, nullptr, context, out, nan_flags,
                       workspace, workspace_bytes, stream);
 }
@@ -758,6 +759,7 @@ int32_t dl_egnn_forward_fc_large(const dl_model* m, int32_t B, int32_t N, const 
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !xh || !t || !node_mask || !edge_mask || !out || !nan_flags || !workspace) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
+    if (m->cfg.attention || m->cfg.tanh || m->cfg.aggregation_mean) return DL_ERR_UNSUPPORTED;   // optional hparams: LDS-resident kernels only
     if (B < 0 || N < 1) return DL_ERR_BAD_ARG;
     return run_sparse(m, B, N, 3, xh, t, t_is_scalar, node_mask, linker_mask, edge_mask, context, out, nan_flags, workspace,
                       workspace_bytes, stream);

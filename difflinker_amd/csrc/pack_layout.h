@@ -30,9 +30,9 @@ constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
 // GCL: units W1a', W1b', W3a', W3b', W4' (node-fragment order), W2' (LDS image of the sparse kernels: pairs are the
 // MFMA rows), W2' again as the LDS image of the LDS-resident kernels (features are the MFMA rows, see egnn_fc.hip), vectors
 constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT, G_W2T = 6 * UNIT;
-constexpr int G_VEC = 7 * UNIT;                       // b1', wr', wd', b2', b3', b4   (6 x 128)
-constexpr int G_SCALE = G_VEC + 6 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max
-constexpr int GCL_SIZE = 7 * UNIT + 6 * HID + 8;
+constexpr int G_VEC = 7 * UNIT;                       // b1', wr', wd', b2', b3', b4, w_att'   (7 x 128)
+constexpr int G_SCALE = G_VEC + 7 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max, b_att
+constexpr int GCL_SIZE = 7 * UNIT + 7 * HID + 12;
 // equivariant update: units W5a', W5b', W6' (both LDS images), vectors
 constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT, E_W6T = 3 * UNIT;
 constexpr int E_VEC = 4 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
@@ -43,6 +43,8 @@ constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
 struct ModelDims {
     int nf, ctx, fin, n_layers;
     float norm_constant;
+    int attention, tanh, mean;     // optional hyper-parameters (fully-connected kernels only)
+    float coords_range, inv_norm;
 };
 
 inline ModelDims dims_of(const dl_model* m) {
@@ -52,6 +54,8 @@ inline ModelDims dims_of(const dl_model* m) {
     md.fin = md.nf + 1 + md.ctx;
     md.n_layers = m->cfg.n_layers;
     md.norm_constant = m->cfg.norm_constant;
+    md.attention = m->cfg.attention; md.tanh = m->cfg.tanh; md.mean = m->cfg.aggregation_mean;
+    md.coords_range = m->cfg.coords_range; md.inv_norm = 1.0f / m->cfg.normalization_factor;
     return md;
 }
 
@@ -155,7 +159,7 @@ __device__ __forceinline__ BFrag load_bfrag(const float* __restrict__ unit_nt, i
 // ---- counter-based noise: Philox4x32-10 keyed by the caller's seed; the counter is
 // (global molecule index, atom position inside the molecule, draw index, component / 4), so a sample does not depend on
 // the batch split across GPUs, on the batch size or on the padded width.  Four 32-bit outputs -> four standard normals
-// by Box-Muller on (u + 0.5) * 2^-32.  Restated for the CPU in oracle/philox_oracle.py.
+// by Box-Muller on 24-bit uniforms ((r >> 8) + 0.5) * 2^-24, i.e. |z| <= sqrt(2 ln 2^25) ~ 5.9.  Restated for the CPU in oracle/philox_oracle.py.
 __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
                                               unsigned (&out)[4]) {
 #pragma unroll

@@ -4,8 +4,8 @@ collective; only the final frames are exchanged, by ONE all-gather (RCCL over xG
 process group's backend is ``nccl``; ``gloo`` in the CPU tests).
 
 One process per GPU (``torch.distributed``); rank r takes a contiguous slice of the collated
-batch.  Noise is drawn for the GLOBAL batch in the reference's call order and sliced, so the
-sample of molecule b does not depend on the world size.
+batch.  Noise comes from the in-kernel counter-based generator keyed by the GLOBAL molecule index
+(or from an explicit global bank, sliced), so the sample of molecule b does not depend on the world size.
 """
 import torch
 import torch.distributed as dist
@@ -62,20 +62,27 @@ def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=N
     """``edm.sample_chain`` on this rank's slice of the batch, then one all-gather of the frames.
 
     ``inputs``: dict with the keyword tensors of ``EDM.sample_chain`` for the FULL batch (already on
-    this rank's device).  ``noise_bank``: optional global ``(noise_x, noise_h)``; when absent each rank
-    draws the global bank from its generator — seed all ranks identically for world-size-independent
-    samples."""
+    this rank's device).  Noise: with more than one rank the draws are generated inside the kernels by the
+    counter-based generator (``noise_source='philox'``, keyed by seed and GLOBAL molecule index: no rank ever
+    materialises the global bank, and a sample does not depend on the world size); every rank must hold the same
+    ``edm.noise_seed``.  ``edm.noise_source = 'torch'`` is honoured only when the caller hands over the global
+    ``noise_bank`` explicitly (parity tests): drawing the reference's ``torch.randn`` stream for the whole batch on every
+    rank costs the full bank (2.5 GB at config C3) and the full ``randn`` work per GPU."""
+    from .edm import InpaintingEDM
+    if isinstance(edm, InpaintingEDM):
+        raise NotImplementedError('sample_chain_sharded drives EDM.sample_chain; InpaintingEDM draws a different noise '
+                                  'sequence (p and q draws per step) and is not wired to the sharded entry point')
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     bs, n = inputs['x'].shape[0], inputs['x'].shape[1]
     local, (lo, hi) = shard_sampler_inputs(inputs, rank, world)
     kw = {}
-    if noise_bank is None and getattr(edm, 'noise_source', 'torch') == 'philox':
-        kw['mol_offset'] = lo                 # counter-based draws: nothing to generate or slice, any world size
-    elif noise_bank is None and world > 1:
-        noise_bank = edm.draw_noise_bank(bs, n, inputs['x'].device)
+    source = getattr(edm, 'noise_source', 'torch')
     if noise_bank is not None:
         kw['noise_bank'] = (noise_bank[0][:, lo:hi].contiguous(), noise_bank[1][:, lo:hi].contiguous())
+    elif source == 'philox' or world > 1:
+        kw['mol_offset'] = lo                 # counter-based draws: nothing to generate or slice, any world size
+        edm.noise_source = 'philox'
     pinned = getattr(edm, 'coef_batch', None)
     if pinned is None:
         edm.coef_batch = bs                  # per-step scalars of the WHOLE batch (see EDM.coef_batch)
@@ -83,4 +90,5 @@ def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=N
         chain = edm.sample_chain(keep_frames=keep_frames, **local, **kw)
     finally:
         edm.coef_batch = pinned
+        edm.noise_source = source
     return all_gather_frames(chain, bs, group) if gather else chain

@@ -8,8 +8,15 @@ denoiser calls.  The noise is drawn up front with the reference's ``torch.randn`
 (x-part then h-part, 2(T+2) calls on the tensors' device), so the same ``torch.manual_seed`` gives
 the same noise stream as the reference run on the same device.
 
-Out of scope (training only): ``EDM.forward`` and the likelihood/KL terms (edm.py:41-124, 244-326),
-``InpaintingEDM`` (edm.py:466-730), the learned ``GammaNetwork`` schedule.
+``InpaintingEDM`` (edm.py:466-727, sampling side) is here too: one HIP denoiser call + one fused HIP tail per step.
+
+Parity note: the per-step scalars (gamma lookup, expm1 / softplus / logsigmoid algebra) are evaluated on CPU fp32 tensors
+of the reference's ``[B,1]`` shape (``step_coefficients``).  The reference evaluates them on the tensors' device; the
+cancellation in sigma^2_{t|s} amplifies a 1-ulp difference of a device's transcendental to ~2e-5, so "same seed, same
+samples" is claimed — and tested (golden fixtures) — against the reference run on the CPU.
+
+Out of scope (training only): ``EDM.forward`` and the likelihood/KL terms (edm.py:41-124, 244-326), the learned
+``GammaNetwork`` schedule.
 """
 import ctypes
 
@@ -237,10 +244,12 @@ class EDM(torch.nn.Module):
         else:
             assert keep_frames <= self.T
         if not self._fused_ok() or not self.dynamics.fits_lds(node_mask):
+            philox_draws = None
             if noise_bank is None and self.noise_source == 'philox':
-                noise_bank = self.philox_noise_bank(x.size(0), x.size(1), x.device, mol_offset)
+                philox_draws = (int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset))   # one draw per step, no bank
+                self.noise_seed = int(self.noise_seed) + 1
             return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
-                                                keep_frames, noise_bank)
+                                                keep_frames, noise_bank, philox_draws)
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.EDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
@@ -267,6 +276,9 @@ class EDM(torch.nn.Module):
         fm, lm = f32(fragment_mask, (bs, n)), f32(linker_mask, (bs, n))
         em = edge_mask.reshape(bs, n, n).to(torch.int8).contiguous() if edge_mask is not None else None
         ctx = f32(context, (bs, n, self.dynamics.context_node_nf)) if context is not None else None
+        # longest-processing-time order: a molecule holds one compute unit for the whole chain and a workgroup's cost grows
+        # with n_b^2, so the big ones are launched first (matters once the batch exceeds the number of compute units)
+        order = torch.argsort(nm.ne(0).sum(1), descending=True, stable=True).to(torch.int32).contiguous()
         chain = torch.zeros((keep_frames, bs, n, self.n_dims + nf), device=dev)
         flags = torch.zeros(bs, dtype=torch.int32, device=dev)
         steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
@@ -279,7 +291,7 @@ class EDM(torch.nn.Module):
             noise_seed=seed, mol_offset=int(mol_offset), reserved=0, coefs=coefs.data_ptr(),
             inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
             norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
-            chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr())
+            chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr(), order=order.data_ptr())
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if getattr(self, 'profile_events', False):     # bench.py: HIP events right around the launch
@@ -321,8 +333,18 @@ class EDM(torch.nn.Module):
             first = int(st[f != 0].min())
             raise utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
 
+    def _philox_draw(self, seed, mol_offset, k, n_samples, n_nodes, device):
+        """Draw number ``k`` of the in-kernel stream as one ``[B,N,3+nf]`` tensor (``dl_philox_fill`` with one draw)."""
+        nx = torch.empty((1, n_samples, n_nodes, self.n_dims), device=device)
+        nh = torch.empty((1, n_samples, n_nodes, self.in_node_nf), device=device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            _lib.check(_lib.load().dl_philox_fill(seed, mol_offset, n_samples, n_nodes, self.in_node_nf, k, 1, nx.data_ptr(),
+                                                  nh.data_ptr(), ctypes.c_void_p(stream)), 'dl_philox_fill')
+        return torch.cat([nx[0], nh[0]], dim=2)
+
     def _sample_chain_host_loop(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames,
-                                noise_bank=None):
+                                noise_bank=None, philox_draws=None):
         """Reference-shaped loop for dynamics the fused kernel does not cover (pockets): one HIP denoiser call
         and one fused HIP tail per step (edm.py:126-176).  Noise: the reference's ``torch.randn`` call order,
         or the given bank ``(noise_x [T+2,B,N,3], noise_h [T+2,B,N,nf])``."""
@@ -335,6 +357,8 @@ class EDM(torch.nn.Module):
             draw_idx[0] += 1
             if noise_bank is not None:
                 return torch.cat([noise_bank[0][k].to(dev, torch.float32), noise_bank[1][k].to(dev, torch.float32)], dim=2)
+            if philox_draws is not None:
+                return self._philox_draw(philox_draws[0], philox_draws[1], k, n_samples, n_nodes, dev)
             return torch.cat([torch.randn((n_samples, n_nodes, self.n_dims), device=dev),
                               torch.randn((n_samples, n_nodes, self.in_node_nf), device=dev)], dim=2)
 
@@ -426,7 +450,13 @@ class InpaintingEDM(EDM):
 
     @torch.no_grad()
     def sample_chain(self, x, h, node_mask, edge_mask, fragment_mask, linker_mask, context, keep_frames=None,
-                     noise_bank=None):
+                     noise_bank=None, mol_offset=0):
+        """``InpaintingEDM.sample_chain`` (edm.py:549-610).  Noise: the reference's ``torch.randn`` sequence (or an explicit
+        bank of ``1 + 2T + 2`` draws); the counter-based in-kernel stream is not defined for the p/q draw pairs of this
+        sampler, so ``noise_source='philox'`` / ``mol_offset`` raise instead of being silently ignored."""
+        if (self.noise_source == 'philox' and noise_bank is None) or mol_offset:
+            raise NotImplementedError("InpaintingEDM draws the reference's torch.randn stream (or an explicit noise_bank); "
+                                      "noise_source='philox' / mol_offset are EDM.sample_chain features")
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.InpaintingEDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
@@ -472,7 +502,7 @@ class InpaintingEDM(EDM):
             return out
 
         def denoise(z_, q_):
-            eps_, flags = self.dynamics._launch_forward(t_arr, z_, None, None, None, None, large=prep['large'], prep=prep)
+            eps_, flags = self.dynamics.launch(prep, t_arr, z_, center=False)      # dl_inpaint_step centres the velocity
             first_bad.masked_fill_((flags != 0) & (seen == 0), q_)
             seen.bitwise_or_(flags)
             return eps_

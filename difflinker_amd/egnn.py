@@ -46,8 +46,8 @@ class GCL(_ParamOnly):
     def __init__(self, input_nf, output_nf, hidden_nf, normalization_factor, aggregation_method, activation,
                  edges_in_d=0, nodes_att_dim=0, attention=False, normalization=None):
         super().__init__()
-        if attention or nodes_att_dim:
-            raise NotImplementedError('attention / node attributes are outside the HIP path')
+        if nodes_att_dim:
+            raise NotImplementedError('node attributes are outside the HIP path')
         self.normalization_factor = normalization_factor
         self.aggregation_method = aggregation_method
         self.attention = attention
@@ -59,14 +59,19 @@ class GCL(_ParamOnly):
                                           activation, nn.Linear(hidden_nf, output_nf), nn.BatchNorm1d(output_nf))
         else:
             raise NotImplementedError(normalization)
+        if attention:                                              # registered last, like the reference (egnn.py:42-43)
+            self.att_mlp = nn.Sequential(nn.Linear(hidden_nf, 1), nn.Sigmoid())
 
 
 class EquivariantUpdate(_ParamOnly):
     """Coordinate MLP (2*hidden+edges_in_d -> hidden -> hidden -> 1, last layer bias-free with
     xavier gain 0.001).  Parameters of reference ``EquivariantUpdate`` (egnn.py:83-99)."""
 
-    def __init__(self, hidden_nf, normalization_factor, aggregation_method, edges_in_d=1, activation=nn.SiLU()):
+    def __init__(self, hidden_nf, normalization_factor, aggregation_method, edges_in_d=1, activation=nn.SiLU(),
+                 tanh=False, coords_range=10.0):
         super().__init__()
+        self.tanh = tanh
+        self.coords_range = coords_range
         head = nn.Linear(hidden_nf, 1, bias=False)                 # created first, like the reference
         torch.nn.init.xavier_uniform_(head.weight, gain=0.001)
         body = _mlp([2 * hidden_nf + edges_in_d, hidden_nf, hidden_nf], activation, last_activation=True)
@@ -79,24 +84,28 @@ class EquivariantBlock(_ParamOnly):
     """``inv_sublayers`` GCLs + one EquivariantUpdate (egnn.py:128-155)."""
 
     def __init__(self, hidden_nf, edge_feat_nf, activation, n_layers, norm_constant, normalization_factor,
-                 aggregation_method):
+                 aggregation_method, attention=False, tanh=False, coords_range=15.0):
         super().__init__()
         self.hidden_nf = hidden_nf
         self.n_layers = n_layers
         self.norm_constant = norm_constant
+        self.coords_range_layer = float(coords_range)
         for i in range(n_layers):
             self.add_module(f'gcl_{i}', GCL(hidden_nf, hidden_nf, hidden_nf, normalization_factor,
-                                            aggregation_method, activation, edges_in_d=edge_feat_nf))
+                                            aggregation_method, activation, edges_in_d=edge_feat_nf, attention=attention))
         self.add_module('gcl_equiv', EquivariantUpdate(hidden_nf, normalization_factor, aggregation_method,
-                                                       edges_in_d=edge_feat_nf, activation=activation))
+                                                       edges_in_d=edge_feat_nf, activation=activation, tanh=tanh,
+                                                       coords_range=self.coords_range_layer))
 
 
 class EGNN(_ParamOnly):
     """Embedding, ``n_layers`` EquivariantBlocks, output projection (egnn.py:181-216)."""
 
     def __init__(self, in_node_nf, hidden_nf, activation, n_layers, norm_constant, inv_sublayers,
-                 normalization_factor, aggregation_method, out_node_nf=None):
+                 normalization_factor, aggregation_method, out_node_nf=None, attention=False, tanh=False, coords_range=15):
         super().__init__()
+        # the reference computes coords_range / n_layers here but hands the UNDIVIDED value to its blocks (egnn.py:192,213)
+        self.coords_range_layer = float(coords_range / n_layers)
         out_node_nf = in_node_nf if out_node_nf is None else out_node_nf
         self.hidden_nf = hidden_nf
         self.n_layers = n_layers
@@ -108,10 +117,10 @@ class EGNN(_ParamOnly):
             self.add_module(f'e_block_{i}', EquivariantBlock(
                 hidden_nf, edge_feat_nf=2, activation=activation, n_layers=inv_sublayers,
                 norm_constant=norm_constant, normalization_factor=normalization_factor,
-                aggregation_method=aggregation_method))
+                aggregation_method=aggregation_method, attention=attention, tanh=tanh, coords_range=coords_range))
 
 
-def egnn_tensor_order(n_layers, inv_sublayers=2):
+def egnn_tensor_order(n_layers, inv_sublayers=2, attention=False):
     """state_dict keys of the EGNN in the order ``dl_model_create`` expects (include/difflinker_hip.h)."""
     keys = ['embedding.weight', 'embedding.bias', 'embedding_out.weight', 'embedding_out.bias']
     for i in range(n_layers):
@@ -119,6 +128,8 @@ def egnn_tensor_order(n_layers, inv_sublayers=2):
             for mlp in ('edge_mlp', 'node_mlp'):
                 for k in (0, 2):
                     keys += [f'e_block_{i}.gcl_{j}.{mlp}.{k}.weight', f'e_block_{i}.gcl_{j}.{mlp}.{k}.bias']
+            if attention:
+                keys += [f'e_block_{i}.gcl_{j}.att_mlp.0.weight', f'e_block_{i}.gcl_{j}.att_mlp.0.bias']
         for k in (0, 2):
             keys += [f'e_block_{i}.gcl_equiv.coord_mlp.{k}.weight', f'e_block_{i}.gcl_equiv.coord_mlp.{k}.bias']
         keys.append(f'e_block_{i}.gcl_equiv.coord_mlp.4.weight')
@@ -154,10 +165,12 @@ class Dynamics(nn.Module):
             # reference: 'gnn_dynamics' builds a plain GNN, anything else NotImplementedError (egnn.py:355-370)
             raise NotImplementedError(f"model={model!r}: the HIP path implements 'egnn_dynamics' only")
         unsupported = []
-        if attention: unsupported.append('attention=True')
-        if tanh: unsupported.append('tanh=True')
+        # attention, tanh and aggregation_method='mean' run in the LDS-resident fully-connected kernels; the pocket /
+        # large-molecule kernels do not carry them (no released configuration uses any of them)
+        if (attention or tanh or aggregation_method != 'sum') and (graph_type != 'FC' or type(self).__name__ != 'Dynamics'):
+            unsupported.append('attention / tanh / mean aggregation with a pocket graph')
         if sin_embedding: unsupported.append('sin_embedding=True')
-        if aggregation_method != 'sum': unsupported.append(f'aggregation_method={aggregation_method!r}')
+        if aggregation_method not in ('sum', 'mean'): unsupported.append(f'aggregation_method={aggregation_method!r}')
         if not isinstance(activation, nn.SiLU): unsupported.append(f'activation={activation!r}')
         if hidden_nf != 128: unsupported.append(f'hidden_nf={hidden_nf}')
         if inv_sublayers != 2: unsupported.append(f'inv_sublayers={inv_sublayers}')
@@ -176,12 +189,14 @@ class Dynamics(nn.Module):
         self.graph_type = graph_type
         self.norm_constant = norm_constant
         self.normalization_factor = normalization_factor
+        self.attention, self.tanh, self.aggregation_method = bool(attention), bool(tanh), aggregation_method
         # `normalization` (batch_norm in the YAMLs) is only forwarded to the GNN branch by the reference
         # (egnn.py:341-368): a no-op for egnn_dynamics, accepted and ignored here too.
         self.dynamics = EGNN(
             in_node_nf=in_node_nf + context_node_nf + int(condition_time), hidden_nf=hidden_nf,
             activation=activation, n_layers=n_layers, norm_constant=norm_constant, inv_sublayers=inv_sublayers,
-            normalization_factor=normalization_factor, aggregation_method=aggregation_method)
+            normalization_factor=normalization_factor, aggregation_method=aggregation_method, attention=attention,
+            tanh=tanh)
         self.n_layers = n_layers
         self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
         self._hip_models = {}                          # device index -> (_HipModel, weight version)
@@ -206,7 +221,8 @@ class Dynamics(nn.Module):
                              hidden_nf=self.dynamics.hidden_nf, n_layers=self.n_layers, inv_sublayers=2,
                              condition_time=1, norm_constant=float(self.norm_constant),
                              normalization_factor=float(self.normalization_factor),
-                             precision=_lib.PRECISIONS[self.precision])
+                             precision=_lib.PRECISIONS[self.precision], attention=int(self.attention), tanh=int(self.tanh),
+                             coords_range=15.0, aggregation_mean=int(self.aggregation_method == 'mean'), sin_embedding=0)
 
     def hip_model(self, device):
         """``dl_model`` handle for ``device`` (packs + uploads the weights on first use / after a change)."""
@@ -220,7 +236,8 @@ class Dynamics(nn.Module):
         if cached is not None and cached[1] == version:
             return cached[0].handle
         sd = self.dynamics.state_dict()
-        host = [sd[k].detach().to('cpu', torch.float32).contiguous() for k in egnn_tensor_order(self.n_layers)]
+        host = [sd[k].detach().to('cpu', torch.float32).contiguous()
+                for k in egnn_tensor_order(self.n_layers, attention=self.attention)]
         cfg = self.hip_config()
         assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == len(host)
         arr = (ctypes.c_void_p * len(host))(*[t.data_ptr() for t in host])
@@ -236,6 +253,9 @@ class Dynamics(nn.Module):
     def _f32(t):
         return None if t is None else t.to(torch.float32).contiguous()
 
+    def _flags(self):
+        return self.attention or self.tanh or self.aggregation_method != 'sum'
+
     def fits_lds(self, node_mask):
         """True when every molecule fits the LDS-resident kernels (<= ``dl_max_atoms()`` real atoms).  Bigger batches run
         on the HBM-resident per-pass kernels (``dl_egnn_forward_fc_large``): same numbers, several times slower."""
@@ -248,26 +268,34 @@ class Dynamics(nn.Module):
         the kernel family); ``launch`` then only enqueues kernels."""
         dev = node_mask.device
         bs, n_nodes = node_mask.shape[0], node_mask.shape[1]
-        return dict(bs=bs, n=n_nodes, dev=dev, large=not self.fits_lds(node_mask),
+        return dict(bs=bs, n=n_nodes, dev=dev, large=not self.fits_lds(node_mask), handle=self.hip_model(dev),
                     nm=node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous(),
                     lm=self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None,
                     em=edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None,
                     ctx=self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None,
                     node_mask3=node_mask.reshape(bs, n_nodes, 1))
 
-    def launch(self, prep, t, xh):
-        """Enqueue one denoiser call for prepared masks; returns ``(eps_hat, nan_flags)`` without synchronising."""
+    def launch(self, prep, t, xh, center=True):
+        """Enqueue one denoiser call for prepared masks; returns ``(eps_hat, nan_flags)`` without synchronising.
+        ``center=False`` skips the centring of a ``centering=True`` denoiser (callers that fuse it into their own tail)."""
         out, flags = self._launch_forward(t, xh, None, None, None, None, large=prep['large'], prep=prep)
-        if self.centering:                                     # inpainting only (egnn.py:444-445)
-            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], prep['node_mask3'].to(out.dtype))
-            out = torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
+        if self.centering and center:                          # inpainting only (egnn.py:444-445)
+            out = self._center_velocity(out, prep['node_mask3'])
         return out, flags
+
+    def _center_velocity(self, out, node_mask3):
+        """``remove_mean_with_mask`` on the velocity part (egnn.py:444-445, utils.py:56-63) without the reference's
+        masking assert, whose ``.item()`` would synchronise the host once per reverse step."""
+        nm = node_mask3.to(out.dtype)
+        vel = out[:, :, :self.n_dims]
+        vel = vel - (vel.sum(1, keepdim=True) / nm.sum(1, keepdim=True)) * nm
+        return torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
 
     def _launch_forward(self, t, xh, node_mask, linker_mask, edge_mask, context, large=False, prep=None):
         lib = _lib.load()
         dev = xh.device
         bs, n_nodes = xh.shape[0], xh.shape[1]
-        handle = self.hip_model(dev)
+        handle = prep['handle'] if prep is not None else self.hip_model(dev)   # a chain packs / looks up the weights once
         xh = self._f32(xh)
         if not torch.is_tensor(t):
             t = torch.tensor([float(t)])
@@ -379,7 +407,7 @@ class DynamicsWithPockets(Dynamics):
         return dict(bs=bs, n=n_nodes, nm=nm, lm=lm, ctx=ctx, ws=ws, need=need, handle=self.hip_model(dev), dev=dev,
                     node_mask3=node_mask.reshape(bs, n_nodes, 1))
 
-    def launch(self, prep, t, xh):
+    def launch(self, prep, t, xh, center=True):
         """Enqueue one denoiser call for prepared masks; returns ``(eps_hat, nan_flags)`` without synchronising."""
         lib = _lib.load()
         dev, bs, n_nodes = prep['dev'], prep['bs'], prep['n']
@@ -396,9 +424,8 @@ class DynamicsWithPockets(Dynamics):
                 prep['handle'], bs, n_nodes, self.GRAPH_TYPES[self.graph_type], _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
                 _lib.ptr(prep['nm']), _lib.ptr(prep['lm']), _lib.ptr(prep['ctx']), _lib.ptr(out), _lib.ptr(flags),
                 _lib.ptr(prep['ws']), prep['need'], ctypes.c_void_p(stream)), 'dl_egnn_forward_pocket')
-        if self.centering:
-            vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], prep['node_mask3'].to(out.dtype))
-            out = torch.cat([vel, out[:, :, self.n_dims:]], dim=2)
+        if self.centering and center:
+            out = self._center_velocity(out, prep['node_mask3'])
         return out, flags
 
     def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 3
+#define DL_ABI_VERSION 4
 
 typedef enum dl_status {
     DL_OK = 0,
@@ -80,11 +80,20 @@ typedef struct dl_config {
     float norm_constant;          /* 1e-6 in the released configs                   */
     float normalization_factor;   /* 100                                            */
     int32_t precision;            /* dl_precision: arithmetic of the 128-wide GEMMs */
+    /* optional hyper-parameters of the reference no released configuration uses; fully-connected path only (the pocket /
+     * large-molecule entry points return DL_ERR_UNSUPPORTED for a model that sets one): */
+    int32_t attention;            /* GCL edge attention: m_ij *= sigmoid(w_att . m_ij + b_att)   src/egnn.py:42-43,52-54  */
+    int32_t tanh;                 /* coordinate head: cdiff * tanh(s) * coords_range             src/egnn.py:104-105      */
+    float coords_range;           /* 15 for Dynamics (EGNN hands its undivided default to the blocks, src/egnn.py:183,213) */
+    int32_t aggregation_mean;     /* 0: sum / normalization_factor; 1: / number of edges of the row, masked ones included
+                                   * (= the padded width N on the fully-connected graph)          src/egnn.py:315-319      */
+    int32_t sin_embedding;        /* must be 0 (src/egnn.py:281-292: not in the kernels)                                   */
 } dl_config;
 
 typedef struct dl_model dl_model; /* opaque: packed, pre-scaled weights resident in HBM */
 
-/* Number of weight tensors dl_model_create expects: 4 + n_layers * (2*8 + 5). */
+/* Number of weight tensors dl_model_create expects: 4 + n_layers * (2*(8 + 2*attention) + 5); with attention every GCL
+ * appends att_mlp.0.weight [1,128] and att_mlp.0.bias [1] after its node_mlp tensors. */
 int32_t dl_model_num_tensors(const dl_config* cfg);
 
 /* Pack the reference's nn.Linear tensors ([out,in] row-major fp32, HOST pointers) into the
@@ -182,6 +191,10 @@ typedef struct dl_chain_args {
     float* chain;               /* device [keep_frames,B,N,3+nf]; frame 0 = final [x, one_hot(h)] */
     int32_t* nan_flags;         /* device [B]  bit0/bit1 as above (first offending forward only) */
     int32_t* nan_step;          /* device [B]  forward index (0..T) at which the flag was raised, or -1 */
+    const int32_t* order;       /* device [B] or NULL: workgroup k samples molecule order[k].  One molecule occupies one
+                                 * compute unit for the whole chain and workgroups are dispatched in index order, so a
+                                 * batch larger than the chip finishes sooner when the big molecules go first
+                                 * (longest-processing-time order); results are written at the molecule's own index. */
 } dl_chain_args;
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);

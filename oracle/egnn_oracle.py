@@ -8,10 +8,13 @@ a "truth" run).  The op ORDER follows the reference (edge list, gather, cat,
 linear, SiLU, mask, scatter-add) so that fp32 results agree with the
 unmodified reference to the last bit or two; pinned by tests/golden.
 
-Scope: the released-config surface only (``egnn_dynamics``, SiLU,
-``attention=False``, ``tanh=False``, ``sin_embedding=False``,
-``aggregation_method='sum'``) — reference ``configs/*.yml``.
+Scope: ``egnn_dynamics`` with SiLU; the optional hyper-parameters ``attention`` (egnn.py:42-43,52-54), ``tanh`` +
+``coords_range`` (:85-99,104-105), ``aggregation_method='mean'`` (:315-319, counting masked edges too) and
+``sin_embedding`` (:281-292) are restated as well (no released config uses them; pinned by
+``tests/golden/fc_forward_flags.npz``).
 """
+import math
+
 from dataclasses import dataclass
 
 import torch
@@ -32,6 +35,12 @@ class EGNNConfig:
     condition_time: bool = True
     graph_type: str = 'FC'         # 'FC' | '4A' | 'FC-4A' | 'FC-10A-4A'
     centering: bool = False
+    attention: bool = False
+    tanh: bool = False
+    coords_range: float = 15.0     # EGNN's default (egnn.py:183).  EGNN computes coords_range / n_layers (:192) but hands the
+                                   # UNDIVIDED value to its blocks (:213), so every EquivariantUpdate uses 15
+    aggregation_method: str = 'sum'
+    sin_embedding: bool = False
 
     @property
     def fin(self):
@@ -59,11 +68,27 @@ def coord2diff(x, row, col, norm_constant=1.0):
     return radial, diff / (norm + norm_constant)
 
 
-def segment_sum(data, row, num_segments, normalization_factor):
-    """``unsorted_segment_sum`` with 'sum' aggregation (egnn.py:304-313)."""
+def segment_sum(data, row, num_segments, normalization_factor, aggregation_method='sum'):
+    """``unsorted_segment_sum`` (egnn.py:304-320): 'sum' divides by the normalisation factor, 'mean' by the number of
+    edges of the segment — every edge of the list counts, masked ones included (the count is taken on ``ones``)."""
     out = data.new_zeros((num_segments, data.size(1)))
-    out.scatter_add_(0, row.unsqueeze(-1).expand(-1, data.size(1)), data)
-    return out / normalization_factor
+    idx = row.unsqueeze(-1).expand(-1, data.size(1))
+    out.scatter_add_(0, idx, data)
+    if aggregation_method == 'sum':
+        return out / normalization_factor
+    assert aggregation_method == 'mean'
+    norm = data.new_zeros(out.shape)
+    norm.scatter_add_(0, idx, data.new_ones(data.shape))
+    norm[norm == 0] = 1
+    return out / norm
+
+
+def sin_embedding(x, max_res=15., min_res=15. / 2000., div_factor=4):
+    """``SinusoidsEmbeddingNew`` (egnn.py:281-292) of squared distances ``[E,1]`` -> ``[E,12]``."""
+    n_freq = int(math.log(max_res / min_res, div_factor)) + 1
+    freq = (2 * math.pi * div_factor ** torch.arange(n_freq) / max_res).to(x.dtype)
+    emb = torch.sqrt(x + 1e-8) * freq[None, :]
+    return torch.cat((emb.sin(), emb.cos()), dim=-1)
 
 
 def _lin(p, key, x):
@@ -78,9 +103,11 @@ def gcl(p, pre, h, row, col, edge_attr, node_mask, edge_mask, cfg):
     inp = torch.cat([h[row], h[col], edge_attr], dim=1)
     m = F.silu(_lin(p, pre + '.edge_mlp.0', inp))
     m = F.silu(_lin(p, pre + '.edge_mlp.2', m))
+    if cfg.attention:                                             # egnn.py:52-54
+        m = m * torch.sigmoid(_lin(p, pre + '.att_mlp.0', m))
     if edge_mask is not None:
         m = m * edge_mask
-    agg = segment_sum(m, row, h.size(0), cfg.normalization_factor)
+    agg = segment_sum(m, row, h.size(0), cfg.normalization_factor, cfg.aggregation_method)
     t = torch.cat([h, agg], dim=1)
     t = F.silu(_lin(p, pre + '.node_mlp.0', t))
     h = h + _lin(p, pre + '.node_mlp.2', t)
@@ -95,10 +122,13 @@ def equivariant_update(p, pre, h, x, row, col, coord_diff, edge_attr, linker_mas
     s = F.silu(_lin(p, pre + '.coord_mlp.0', inp))
     s = F.silu(_lin(p, pre + '.coord_mlp.2', s))
     s = _lin(p, pre + '.coord_mlp.4', s)
-    trans = coord_diff * s
+    if cfg.tanh:                                                  # egnn.py:104-105
+        trans = coord_diff * torch.tanh(s) * float(cfg.coords_range)
+    else:
+        trans = coord_diff * s
     if edge_mask is not None:
         trans = trans * edge_mask
-    agg = segment_sum(trans, row, x.size(0), cfg.normalization_factor)
+    agg = segment_sum(trans, row, x.size(0), cfg.normalization_factor, cfg.aggregation_method)
     if linker_mask is not None:
         agg = agg * linker_mask
     x = x + agg
@@ -110,6 +140,8 @@ def equivariant_update(p, pre, h, x, row, col, coord_diff, edge_attr, linker_mas
 def equivariant_block(p, pre, h, x, row, col, d0, node_mask, linker_mask, edge_mask, cfg):
     """``EquivariantBlock.forward`` egnn.py:157-178."""
     radial, coord_diff = coord2diff(x, row, col, cfg.norm_constant)
+    if cfg.sin_embedding:                                         # egnn.py:160-161
+        radial = sin_embedding(radial)
     edge_attr = torch.cat([radial, d0], dim=1)
     for i in range(cfg.inv_sublayers):
         h = gcl(p, f'{pre}.gcl_{i}', h, row, col, edge_attr, node_mask, edge_mask, cfg)
@@ -123,6 +155,8 @@ def equivariant_block(p, pre, h, x, row, col, d0, node_mask, linker_mask, edge_m
 def egnn_forward(p, pre, h, x, row, col, node_mask, linker_mask, edge_mask, cfg):
     """``EGNN.forward`` egnn.py:218-238 (d0 uses coord2diff's default norm, radial only)."""
     d0, _ = coord2diff(x, row, col)
+    if cfg.sin_embedding:                                         # egnn.py:221-222
+        d0 = sin_embedding(d0)
     h = _lin(p, pre + '.embedding', h)
     for i in range(cfg.n_layers):
         h, x = equivariant_block(p, f'{pre}.e_block_{i}', h, x, row, col, d0,

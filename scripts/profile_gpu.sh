@@ -4,9 +4,9 @@
 #   2. --pmc (own passes, no trace flags) -> MFMA busy / clocks, then FETCH_SIZE, then WRITE_SIZE
 # Everything lands in gpurun_out/prof_$TAG/ ; copy the summaries you want judged into profiles/.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 shift || true
-BENCH_ARGS=${*:---steps 2 --warmup 1 --T 20 --no-cpu-baseline}
+BENCH_ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-secondary}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -15,7 +15,15 @@ run() {  # name, rocprof args...
   local name=$1; shift
   ( cd /tmp && timeout 600 rocprofv3 "$@" -d /tmp/rp_$name --output-format csv -- python $ROOT/bench.py $BENCH_ARGS ) > $OUT/$name.log 2>&1
   echo "[$name] exit $?" >> $OUT/$name.log
-  for f in $(find /tmp/rp_$name -name '*.csv' 2>/dev/null); do cp $f $OUT/${name}_$(basename $f); done
+  # keep the small files only (gpurun merges at most 64 MiB back): the statistics, and of the per-dispatch tables the rows of
+  # this library's kernels (the 1004 torch.randn launches of every chain make the raw tables hundreds of MB)
+  for f in $(find /tmp/rp_$name -name '*.csv' 2>/dev/null); do
+    case $f in
+      *kernel_trace.csv|*counter_collection.csv) (head -1 $f; grep -E "sample_chain_fc|egnn_forward_fc|pk_|sampler_step|size_gnn" $f) > $OUT/${name}_$(basename $f) ;;
+      *) cp $f $OUT/${name}_$(basename $f) ;;
+    esac
+  done
+  rm -rf /tmp/rp_$name
 }
 run trace --kernel-trace --stats
 run pmc_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY

@@ -1,7 +1,7 @@
 """Condense a scripts/profile_gpu.sh output directory (gpurun_out/prof_<tag>/) into the two small files that are kept
 under profiles/: the kernel-trace statistics with the template-heavy PyTorch kernel names shortened, and the PMC
 counters of the dominant kernel averaged over its launches (FETCH_SIZE doubled, MI355X_MICROARCH.md gfx950 note).
-usage: python scripts/summarize_profile.py gpurun_out/prof_r01d profiles/r01_final [kernel substring]"""
+usage: python scripts/summarize_profile.py gpurun_out/prof_r02 profiles/r02 [kernel substring] [forwards per launch]"""
 import csv
 import glob
 import json
@@ -10,11 +10,13 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 kernel = sys.argv[3] if len(sys.argv) > 3 else 'sample_chain_fc_kernel'
+forwards = int(sys.argv[4]) if len(sys.argv) > 4 else 501
+tag = f'T{forwards - 1}'
 os.makedirs(dst, exist_ok=True)
 
 stats = glob.glob(os.path.join(src, 'trace_*_kernel_stats.csv'))[0]
 rows = list(csv.reader(open(stats)))
-with open(os.path.join(dst, 'kernel_stats_T20.csv'), 'w', newline='') as f:
+with open(os.path.join(dst, f'kernel_stats_{tag}.csv'), 'w', newline='') as f:
     w = csv.writer(f)
     for r in rows:
         r[0] = r[0] if len(r[0]) < 140 else r[0][:100] + ' ... ' + r[0][-30:]
@@ -32,7 +34,7 @@ for path in glob.glob(os.path.join(src, 'pmc_*_counter_collection.csv')):
                                   'Accum_VGPR_Count', 'SGPR_Count')}
 out = {k: sums[k] / counts[k] for k in sorted(sums)}
 out['_kernel_meta'] = meta
-d = {'kernel_avg_ms_rocprof': avg_ns / 1e6}
+d = {'kernel_avg_ms_rocprof': avg_ns / 1e6, 'forwards_per_launch': forwards}
 if 'GRBM_GUI_ACTIVE' in out:
     d['gui_active_per_xcd_cycles'] = out['GRBM_GUI_ACTIVE'] / 8
     d['effective_clock_GHz'] = d['gui_active_per_xcd_cycles'] / avg_ns
@@ -42,10 +44,10 @@ if 'FETCH_SIZE' in out:
     d['hbm_fetch_bytes_per_launch_x2_corrected'] = out['FETCH_SIZE'] * 1024 * 2
 if 'WRITE_SIZE' in out:
     d['hbm_write_bytes_per_launch'] = out['WRITE_SIZE'] * 1024
-d['note'] = ('per launch of ' + kernel + ' (T=20: 21 forwards, C2 ragged batch, f16x3); FETCH_SIZE/WRITE_SIZE are in KiB, '
+d['note'] = ('per launch of ' + kernel + ' (' + tag + ': ' + str(forwards) + ' forwards, C2 ragged batch, f16x3); FETCH_SIZE/WRITE_SIZE are in KiB, '
              'FETCH doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); fabric-side counters, '
              'Infinity-Cache hits included: register-spill scratch and per-workgroup weight streaming, the algorithmic '
              'bytes are ~2 MB per forward')
 out['_derived'] = d
-json.dump(out, open(os.path.join(dst, 'pmc_chain_kernel_T20.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(dst, f'pmc_chain_kernel_{tag}.json'), 'w'), indent=1)
 print(json.dumps(d, indent=1))

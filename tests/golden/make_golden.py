@@ -25,7 +25,7 @@ from src.egnn import Dynamics, DynamicsWithPockets      # noqa: E402
 from src.edm import EDM                                 # noqa: E402
 from src.noise import PredefinedNoiseSchedule           # noqa: E402
 
-from helpers import seeded_state_dict, seeded_size_state_dict, GLUE_HPARAMS, glue_cases, glue_molecules, ragged_fc_molecules   # noqa: E402
+from helpers import FLAG_CASES, seeded_state_dict, seeded_size_state_dict, GLUE_HPARAMS, glue_cases, glue_molecules, ragged_fc_molecules   # noqa: E402
 from difflinker_amd import synthetic                    # noqa: E402
 from difflinker_amd.datasets import collate             # noqa: E402
 
@@ -79,6 +79,36 @@ def fc_forward():
     save('fc_forward', nf=nf, ctx=ctx, n_layers=L, weight_seed=21, coord_gain=0.02,
          t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'],
          context=inp['context'], out=out, out_mol1_unpadded=out1)
+
+
+@torch.no_grad()
+def fc_forward_flags():
+    """Dynamics.forward with the optional hyper-parameters no released config uses (egnn.py:42-43,52-54 attention,
+    :104-105 tanh, :315-319 mean aggregation, :281-292 sinusoidal distance embedding), same inputs as ``fc_forward``,
+    plus a padded-width variant for 'mean' (the count is the padded width N, masked edges included)."""
+    nf, ctx, L = 9, 1, 2
+    data = ragged_fc_batch([14, 9, 12, 5], [4, 3, 5, 2], nf, seed=11)
+    inp = synthetic.sampler_inputs(data)
+    g = torch.Generator().manual_seed(12)
+    B, N = inp['x'].shape[:2]
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + \
+        torch.randn((B, N, 3 + nf), generator=g) * inp['linker_mask']
+    t = torch.rand((B, 1), generator=g)
+    out = {}
+    for tag, flags in FLAG_CASES:
+        kw = dict(attention=False, tanh=False, sin_embedding=False, aggregation_method='sum')
+        kw.update(flags)
+        dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, device='cpu', n_layers=L,
+                       norm_constant=1e-6, inv_sublayers=2, normalization_factor=100, model='egnn_dynamics',
+                       normalization='batch_norm', centering=False, graph_type='FC', **kw)
+        sd = seeded_state_dict(nf + ctx + 1, 128, L, 25, coord_gain=1.0 if kw['tanh'] else 0.02, attention=kw['attention'],
+                               edge_feat_nf=24 if kw['sin_embedding'] else 2)
+        dyn.load_state_dict(sd, strict=True)
+        dyn.eval()
+        out['out_' + tag] = dyn.forward(t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'],
+                                        edge_mask=inp['edge_mask'], context=inp['context'])
+    save('fc_forward_flags', nf=nf, ctx=ctx, n_layers=L, weight_seed=25, t=t, xh=z, node_mask=inp['node_mask'],
+         linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'], context=inp['context'], **out)
 
 
 @torch.no_grad()
@@ -391,6 +421,7 @@ if __name__ == '__main__':
         sys.exit(0)
     c1_chain()
     ddpm_glue()
+    fc_forward_flags()
     gamma_tables()
     collate_masks()
     fc_forward()

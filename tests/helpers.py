@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 
-def dynamics_param_shapes(fin, hidden_nf, n_layers, inv_sublayers=2, prefix='dynamics'):
+def dynamics_param_shapes(fin, hidden_nf, n_layers, inv_sublayers=2, prefix='dynamics', attention=False, edge_feat_nf=2):
     """(key, shape, fan_in, kind) for every tensor of the reference ``Dynamics`` state_dict
     (egnn_dynamics), in the reference's registration order (egnn.py:19-30,90-97,203-212)."""
     hn = hidden_nf
@@ -21,25 +21,28 @@ def dynamics_param_shapes(fin, hidden_nf, n_layers, inv_sublayers=2, prefix='dyn
     for i in range(n_layers):
         blk = f'{prefix}.e_block_{i}'
         for j in range(inv_sublayers):
-            lin(f'{blk}.gcl_{j}.edge_mlp.0', hn, 2 * hn + 2)
+            lin(f'{blk}.gcl_{j}.edge_mlp.0', hn, 2 * hn + edge_feat_nf)
             lin(f'{blk}.gcl_{j}.edge_mlp.2', hn, hn)
             lin(f'{blk}.gcl_{j}.node_mlp.0', hn, 2 * hn)
             lin(f'{blk}.gcl_{j}.node_mlp.2', hn, hn)
-        lin(f'{blk}.gcl_equiv.coord_mlp.0', hn, 2 * hn + 2)
+            if attention:                                   # registered after node_mlp (egnn.py:42-43)
+                lin(f'{blk}.gcl_{j}.att_mlp.0', 1, hn)
+        lin(f'{blk}.gcl_equiv.coord_mlp.0', hn, 2 * hn + edge_feat_nf)
         lin(f'{blk}.gcl_equiv.coord_mlp.2', hn, hn)
         out.append((f'{blk}.gcl_equiv.coord_mlp.4.weight', (1, hn), hn, 'coord'))
     return out
 
 
 def seeded_state_dict(fin, hidden_nf, n_layers, seed, coord_gain=0.02, inv_sublayers=2, prefix='dynamics',
-                      dtype=torch.float32):
+                      dtype=torch.float32, attention=False, edge_feat_nf=2):
     """Weights from ``numpy.random.default_rng(seed)`` (PCG64: stable across versions), shaped
     like ``nn.Linear``'s default init (U(-1/sqrt(fan_in), 1/sqrt(fan_in))); the coordinate head
     uses xavier-uniform with ``coord_gain`` (0.001 = reference default egnn.py:90-91; 0.02 keeps
     T=500 chains finite but lively)."""
     rng = np.random.default_rng(seed)
     sd = {}
-    for key, shape, fan_in, kind in dynamics_param_shapes(fin, hidden_nf, n_layers, inv_sublayers, prefix):
+    for key, shape, fan_in, kind in dynamics_param_shapes(fin, hidden_nf, n_layers, inv_sublayers, prefix, attention,
+                                                          edge_feat_nf):
         if kind == 'coord':
             bound = coord_gain * math.sqrt(6.0 / (shape[0] + shape[1]))
         else:
@@ -166,3 +169,12 @@ def glue_molecules(pockets, nf, seed):
     return mols
 
 
+
+
+FLAG_CASES = [                       # optional hyper-parameters of Dynamics (tests/golden/fc_forward_flags.npz)
+    ('attention', dict(attention=True)),
+    ('tanh', dict(tanh=True)),
+    ('mean', dict(aggregation_method='mean')),
+    ('all', dict(attention=True, tanh=True, aggregation_method='mean')),
+    ('sin', dict(sin_embedding=True)),
+]

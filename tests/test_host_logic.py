@@ -26,7 +26,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dl_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.dl_abi_version() == _lib.ABI_VERSION == 4
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
     cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
@@ -48,12 +48,25 @@ def test_no_gpu_means_loud_failure_not_fallback():
 
 def test_unsupported_hparams_raise():
     from difflinker_amd import Dynamics
-    for kw in (dict(attention=True), dict(tanh=True), dict(sin_embedding=True), dict(aggregation_method='mean'),
-               dict(hidden_nf=64), dict(model='gnn_dynamics')):
+    for kw in (dict(sin_embedding=True), dict(aggregation_method='max'), dict(hidden_nf=64), dict(model='gnn_dynamics')):
         args = dict(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1)
         args.update(kw)
         with pytest.raises(NotImplementedError):
             Dynamics(**args)
+
+
+def test_optional_hparams_own_the_reference_parameters():
+    """attention / tanh / mean are accepted on the fully-connected path; attention adds ``att_mlp.0`` to every GCL in the
+    reference's registration order (egnn.py:42-43), and the C-ABI tensor order carries it."""
+    from difflinker_amd import Dynamics
+    from difflinker_amd.egnn import egnn_tensor_order
+    dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=2, norm_constant=1e-6, attention=True, tanh=True, aggregation_method='mean')
+    expect = dynamics_param_shapes(11, 128, 2, attention=True)
+    assert [k for k, _ in dyn.state_dict().items()] == [e[0] for e in expect]
+    order = egnn_tensor_order(2, attention=True)
+    assert len(order) == 4 + 2 * (2 * 10 + 5) and 'e_block_1.gcl_0.att_mlp.0.bias' in order
+    cfg = dyn.hip_config()
+    assert (cfg.attention, cfg.tanh, cfg.aggregation_mean, cfg.sin_embedding) == (1, 1, 1, 0) and cfg.coords_range == 15.0
 
 
 def test_state_dict_keys_and_tensor_order():
