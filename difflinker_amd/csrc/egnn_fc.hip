@@ -446,7 +446,11 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     for (int k = 0; k < 4; ++k) {
                         const int reg = 4 * qq + k;
                         const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
+#if defined(DL_KO_TRANS)
+                        const float u2 = y2 * fmaf(y2, 0.25f, 0.5f);
+#else
                         const float u2 = silu_u(y2);
+#endif
                         if (EQUIV || ATT) ssum = fmaf(ww[k], u2, ssum);
                         if (ATT) c2[reg] = u2;                       // the message waits for its attention weight
                         else if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
@@ -537,27 +541,44 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     Pq[buf] = *reinterpret_cast<const float4*>(Pp + 32 * mt + 8 * qd);
                     Qq[buf] = *reinterpret_cast<const float4*>(Qp + 32 * mt + 8 * qd);
                 };
+                // (DL_KO_*: knock-out switches of the energy / timing experiments under profiles/; never set in the product build)
                 auto load_a = [&](int slab, int oh, int buf) {
+#ifdef DL_KO_WREAD
+                    af[buf][0] = fh[0][0]; af[buf][1] = fl[0][0]; af[buf][2] = fh[0][1]; af[buf][3] = fl[0][1];
+#else
                     af[buf][0] = Wq[(slab * 4 + 2 * oh) * 64]; af[buf][1] = Wq[(slab * 4 + 2 * oh + 1) * 64];
                     af[buf][2] = Wq[((8 + slab) * 4 + 2 * oh) * 64]; af[buf][3] = Wq[((8 + slab) * 4 + 2 * oh + 1) * 64];
+#endif
                 };
                 // the three VALU chunks of element pair e (registers 2e, 2e+1) of the tile in production
                 auto chunk_a = [&](int e) {
                     const float4 P = Pq[(e >> 1) & 1], Q = Qq[(e >> 1) & 1];
                     const float p0 = (e & 1) ? P.z + Q.z : P.x + Q.x, p1 = (e & 1) ? P.w + Q.w : P.y + Q.y;
                     yy[0] = fmaf(g1[2 * e], invS1, p0); yy[1] = fmaf(g1[2 * e + 1], invS1, p1);
+#ifdef DL_KO_TRANS
+                    ee[0] = yy[0] * 0.25f; ee[1] = yy[1] * 0.25f;
+#else
                     ee[0] = __builtin_amdgcn_exp2f(yy[0]); ee[1] = __builtin_amdgcn_exp2f(yy[1]);
+#endif
                 };
                 auto chunk_b = [&]() {
                     // SiLU in u-form, scaled into the fp16 range: y * sa / (1 + 2^y)
+#ifdef DL_KO_TRANS
+                    ee[0] = fmaf(ee[0], isa, isa) * 0.5f; ee[1] = fmaf(ee[1], isa, isa) * 0.5f;
+#else
                     ee[0] = __builtin_amdgcn_rcpf(fmaf(ee[0], isa, isa)); ee[1] = __builtin_amdgcn_rcpf(fmaf(ee[1], isa, isa));
+#endif
                 };
                 auto chunk_c = [&](int e, int buf) {
                     uu[0] = yy[0] * ee[0]; uu[1] = yy[1] * ee[1];
+#ifdef DL_KO_SPLIT
+                    const unsigned hp = __float_as_uint(uu[0]) & 0x3bff3bffu, lp = __float_as_uint(uu[1]) & 0x3bff3bffu;
+#else
                     const float h0 = __uint_as_float(__float_as_uint(uu[0]) & 0xffffe000u);
                     const float h1 = __uint_as_float(__float_as_uint(uu[1]) & 0xffffe000u);
                     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
                     const unsigned lp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(uu[0] - h0, uu[1] - h1));
+#endif
                     const int sl = e >> 2, d = e & 3;           // slab of the tile, dword of the fragment
                     if (d == 0) { fh[buf][sl].x = hp; fl[buf][sl].x = lp; }
                     if (d == 1) { fh[buf][sl].y = hp; fl[buf][sl].y = lp; }
@@ -569,7 +590,11 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     const int grp = i / 6, m6 = i % 6, sl = grp >> 1, oh = grp & 1, buf = grp & 1;
                     const uint4& a = af[buf][(m6 < 2 ? 2 : 0) + (m6 & 1)];          // lo, lo, hi, hi, hi, hi
                     const uint4& b = (m6 == 2 || m6 == 3) ? fl[k & 1][sl] : fh[k & 1][sl];
+#ifdef DL_KO_MFMA2
+                    c2[2 * oh + (m6 & 1)][i & 15] += __uint_as_float((a.x ^ b.y) & 0x3fffffffu);
+#else
                     c2[2 * oh + (m6 & 1)] = mfma_h(a, b, c2[2 * oh + (m6 & 1)]);
+#endif
                 };
 
                 // prologue: tile 0 of the first layer (no MFMAs to hide under yet), first W2' group, first rows
