@@ -92,6 +92,16 @@ for w in range(8):
         if key in inloop:
             loop[kind][inloop[key]] = loop[kind].get(inloop[key], 0) + ts[k + 1] - ts[k]
             if key == (40, 41): cnt[kind] += 1
+    segs = [(tg, t_) for tg, t_ in zip(tags, ts) if tg >= 40]
+    if segs and w in (0, 4):
+        # ping-pong builds: (40+k) = segment k of steps 2..3 finished, (60+k) = barrier k released; first pass only
+        first = []
+        for tg, t_ in segs:
+            if first and tg == 40 and any(x[0] == 40 for x in first):
+                break
+            first.append((tg, t_))
+        line = ' '.join(f'{tg}:{t_ - first[0][1]}' for tg, t_ in first)
+        print(f'   wave {w} segment log (tag:ticks since first): {line}')
     print(f'wave {w}: gcl PAIR {tot.get("gcl: PAIR loop + partials", 0):9d}  eq PAIR {tot.get("eq: PAIR loop + partials", 0):9d}  total {total}')
     if w in (0, 4, 7):
         print(f'--- wave {w}: {n} events, total {total} ticks')
