@@ -7,7 +7,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 #define N_ITER 2048
 
-template <int NACC, int LDSREADS, int PARTNER>   // PARTNER 0: same code, 1: VALU mix, 2: idle
+template <int NACC, int LDSREADS, int PARTNER, int VPRIO = 0>   // PARTNER 0: same code, 1: VALU mix, 2: idle; VPRIO: s_setprio of the VALU waves
 __global__ void __launch_bounds__(512) k(float* out, float seed, int nwaves) {
     __shared__ uint4 wbuf[4096];            // 64 KB
     for (int i = threadIdx.x; i < 4096; i += blockDim.x) wbuf[i] = make_uint4(i, i + 1, i + 2, i + 3);
@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(512) k(float* out, float seed, int nwaves) {
     if (PARTNER == 2 && w < 4) return;
     const uint4* Wq = wbuf + lane;
     if (PARTNER >= 1 && w >= 4) {
+        if (VPRIO) __builtin_amdgcn_s_setprio(VPRIO);
         for (int o = 0; o < N_ITER; ++o) {
 #pragma unroll
             for (int m = 0; m < 480; ++m) {
@@ -68,14 +69,14 @@ __global__ void __launch_bounds__(512) k(float* out, float seed, int nwaves) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s_;
 }
 
-template <int NACC, int LDSREADS, int PARTNER>
+template <int NACC, int LDSREADS, int PARTNER, int VPRIO = 0>
 void run(const char* name, int nwaves) {
     static float* out = nullptr;
     if (!out) hipMalloc(&out, 256 * 512 * 4);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<NACC, LDSREADS, PARTNER>), dim3(256), dim3(512), 0, 0, out, 1.0f, nwaves);
+    hipLaunchKernelGGL((k<NACC, LDSREADS, PARTNER, VPRIO>), dim3(256), dim3(512), 0, 0, out, 1.0f, nwaves);
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<NACC, LDSREADS, PARTNER>), dim3(256), dim3(512), 0, 0, out, 1.0f, nwaves);
+    hipLaunchKernelGGL((k<NACC, LDSREADS, PARTNER, VPRIO>), dim3(256), dim3(512), 0, 0, out, 1.0f, nwaves);
     hipEventRecord(e1, 0);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -94,5 +95,12 @@ int main() {
     run<2, 1, 1>("2 acc + LDS | partner: 144 exp + 336 fmac", 8);
     run<2, 0, 1>("2 acc regs | partner: 144 exp + 336 fmac", 8);
     run<2, 1, 2>("partner alone: 144 exp + 336 fmac (waves 4-7 only)", 8);
+    run<4, 0, 1>("4 acc regs | partner: 144 exp + 336 fmac", 8);
+    run<4, 1, 1>("4 acc + LDS | partner: 144 exp + 336 fmac", 8);
+    run<1, 0, 1>("1 acc regs | partner: 144 exp + 336 fmac", 8);
+    run<1, 1, 1>("1 acc + LDS | partner: 144 exp + 336 fmac", 8);
+    run<2, 0, 1, 3>("2 acc regs | partner at s_setprio 3", 8);
+    run<2, 1, 1, 3>("2 acc + LDS | partner at s_setprio 3", 8);
+    run<4, 0, 1, 1>("4 acc regs | partner at s_setprio 1", 8);
     return 0;
 }
