@@ -413,6 +413,28 @@ def ddpm_glue():
     save('ddpm_glue', T=6, **out)
 
 
+def xyz_writer():
+    """``save_xyz_file`` of the reference (src/visualizer.py:14-31) run itself (its module imports imageio / matplotlib /
+    RDKit-bound helpers at the top: stand-ins from ``_stub_reference_dependencies``): the text of the files it writes."""
+    import tempfile
+    _stub_reference_dependencies()
+    from src.visualizer import save_xyz_file
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for tag, nf, is_geom in (('zinc', 8, False), ('geom', 9, True)):
+        B, N = 3, 7
+        one_hot = torch.nn.functional.one_hot(torch.randint(0, nf, (B, N), generator=g), nf).float()
+        pos = 10.0 * torch.randn((B, N, 3), generator=g)
+        mask = (torch.rand((B, N, 1), generator=g) > 0.3).float()
+        mask[:, 0] = 1
+        with tempfile.TemporaryDirectory() as d:
+            save_xyz_file(d, one_hot, pos, mask, names=[f'm{i}' for i in range(B)], is_geom=is_geom, suffix='x')
+            text = [open(os.path.join(d, f'm{i}_x.xyz')).read() for i in range(B)]
+        out[f'{tag}_one_hot'], out[f'{tag}_pos'], out[f'{tag}_mask'] = one_hot, pos, mask
+        out[f'{tag}_text'] = np.array(text)
+    save('xyz_writer', **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                                  # regenerate selected fixtures only
@@ -422,6 +444,7 @@ if __name__ == '__main__':
     c1_chain()
     ddpm_glue()
     fc_forward_flags()
+    xyz_writer()
     gamma_tables()
     collate_masks()
     fc_forward()

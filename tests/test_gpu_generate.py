@@ -173,3 +173,32 @@ def test_sample_trajectories_driver(tmp_path):
     assert len(read_xyz(os.path.join(final_dir, '1_pred_.xyz'))[0]) == 7 + 3
     # frame 0 of the chain is the final sample
     assert open(os.path.join(chains_dir, '1', '1_0_.xyz')).read() == open(os.path.join(final_dir, '1_pred_.xyz')).read()
+
+
+@pytest.mark.parametrize('case,anchors', [('hsp90', '12,22'), ('jnk', None)])
+def test_generate_with_protein_on_the_reference_case_studies(tmp_path, case, anchors):
+    """The reference's own inputs (case_studies/hsp90: 3hz1 fragments with anchors 12,22 as in its README;
+    case_studies/jnk: 3fi3 fragments), protein trimmed to 12 A around the fragments: the 6 A pocket of several hundred
+    atoms (N ~ 350-450, the host-driven pocket chain) goes through ``generate_with_protein`` end to end."""
+    from difflinker_amd import DDPM, io
+    from difflinker_amd.generate import generate_with_protein
+    from oracle import io_oracle
+    cdir = os.path.join(IO_DIR, 'case_studies')
+    sdf, pdb = os.path.join(cdir, f'{case}_fragments.sdf'), os.path.join(cdir, f'{case}_protein_12A.pdb')
+    hp = ddpm_hparams(True)
+    if anchors:
+        hp.update(anchors_context=True, context_node_nf=3, center_of_mass='anchors')
+    torch.manual_seed(0)
+    ddpm = DDPM(**hp)
+    frag = io.read_molecule(sdf)
+    pocket_pos, pocket_sym = io_oracle.pocket_of_protein(pdb, np.asarray(frag.positions, dtype=np.float64))
+    assert 150 < len(pocket_sym) < 600
+    files = generate_with_protein(sdf, pdb, backbone_atoms_only=False, model=ddpm, output_dir=str(tmp_path / case),
+                                  n_samples=3, n_steps=4, linker_size='5', anchors=anchors, random_seed=3)
+    assert len(files) == 3
+    for f in files:
+        syms, pos = read_xyz(f)
+        assert len(syms) == len(frag) + 5, 'fragments + linker only: the pocket atoms stay out of the file'
+        assert syms[:len(frag)] == list(frag.symbols)
+        assert np.abs(pos[:len(frag)] - np.asarray(frag.positions)).max() <= 2e-4, 'fragments return to the input frame'
+        assert np.isfinite(pos).all()

@@ -116,3 +116,43 @@ def test_generation_driver_helpers(tmp_path):
     em = out['edge_mask'].view(5, 5)
     assert em[:2, :2].tolist() == [[-2, -1], [-1, -2]] and float(em[2:].abs().sum() + em[:, 2:].abs().sum()) == 0.0
     assert out['atom_mask'].view(-1).tolist() == [1, 1, 1, 1, 1] and len(out['edges'][0]) == 25
+
+
+# ---- the reference's own case-study inputs (tests/golden/io/case_studies, made by make_case_studies.py) ---------------
+CASE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'io', 'case_studies')
+
+
+@pytest.mark.parametrize('case,n_frag', [('hsp90', 23), ('jnk', 29)])
+def test_case_study_fragments_and_pocket_against_the_io_oracle(case, n_frag):
+    """``read_molecule`` / ``get_pocket`` on real inputs (3hz1 / 3fi3 fragments, proteins trimmed to 12 A) against the
+    independent restatement in oracle/io_oracle.py (RDKit / Bio.PDB themselves are absent: their parsing stays unpinned)."""
+    from difflinker_amd import io
+    from oracle import io_oracle
+    sdf = os.path.join(CASE_DIR, f'{case}_fragments.sdf')
+    pdb = os.path.join(CASE_DIR, f'{case}_protein_12A.pdb')
+    mol = io.read_molecule(sdf)
+    syms, xyz = io_oracle.heavy_atoms_of_sdf(sdf)
+    assert len(mol) == n_frag == len(syms) and list(mol.symbols) == syms
+    assert np.array_equal(np.asarray(mol.positions, dtype=np.float64), xyz)
+    for bb in (False, True):
+        pos, one_hot, charges = io.get_pocket(mol, pdb, backbone_atoms_only=bb)
+        want_pos, want_sym = io_oracle.pocket_of_protein(pdb, xyz, backbone_atoms_only=bb)
+        assert pos.shape == want_pos.shape and len(want_sym) > 50
+        assert np.array_equal(np.asarray(pos, dtype=np.float32), want_pos)
+        from difflinker_amd import const
+        assert [const.GEOM_IDX2ATOM[int(k)] for k in one_hot.argmax(1)] == want_sym
+        assert charges.tolist() == [io_oracle.GEOM_ATOMS[s] for s in want_sym]
+    # the trimmed protein still holds residues the 6 A rule rejects
+    n_all = sum(1 for ln in open(pdb) if ln.startswith('ATOM'))
+    assert len(want_sym) < n_all
+
+
+def test_save_xyz_file_writes_what_the_reference_writes(tmp_path):
+    """Text of the files against ``src/visualizer.py::save_xyz_file`` itself (fixture xyz_writer.npz)."""
+    from difflinker_amd import io
+    z = np.load(os.path.join(os.path.dirname(CASE_DIR), '..', 'xyz_writer.npz'))
+    for tag, is_geom in (('zinc', False), ('geom', True)):
+        one_hot, pos, mask = (torch.from_numpy(z[f'{tag}_{k}']) for k in ('one_hot', 'pos', 'mask'))
+        io.save_xyz_file(str(tmp_path), one_hot, pos, mask, names=[f'm{i}' for i in range(3)], is_geom=is_geom, suffix='x')
+        for i in range(3):
+            assert open(tmp_path / f'm{i}_x.xyz').read() == str(z[f'{tag}_text'][i])
