@@ -384,13 +384,12 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             }
         }
 
-        // mask value of step t (0 past the end of the slot's range); the raw byte is converted where it is used, so the
-        // wait for the load lands there and not right behind its issue
+        // raw mask byte of step t; it is converted (and zeroed past the end of the slot's range) where it is used, a whole
+        // step later, so the wait for the global load lands there and not right behind its issue
         auto load_mask = [&](int t) -> int {
-            if (mrow == nullptr) return (t < jn) ? 1 : 0;
+            if (mrow == nullptr) return 1;
             const int jj = (t < jn) ? j0 + t : j0;                 // always a valid row (the slot is empty when jn <= 0)
-            const int raw = (jn > 0) ? int(mrow[v.idx[min(jj, nb - 1)]]) : 0;
-            return (t < jn) ? raw : 0;
+            return (jn > 0) ? int(mrow[v.idx[min(jj, nb - 1)]]) : 0;       // steps past the range: see `ok` at the uses
         };
         int m_next = load_mask(0);
 
@@ -510,7 +509,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     c2[2] = mfma32(a4.z, bv, c2[2]);
                     c2[3] = mfma32(a4.w, bv, c2[3]);
                 }
-                const float m = float(m_raw);
+                const float m = ok ? float(m_raw) : 0.0f;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     TileVecs tv = load_vecs(mt);
@@ -522,37 +521,41 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 // is blocked at an MFMA while the matrix pipe is busy, so a phase-separated stream (all SiLUs, then all MFMAs)
                 // costs VALU time + MFMA time per wave, and the SIMD's second wave - running the same phases - hides little of
                 // it (measured: 10.8 K cycles per step alone, 16.6 K with the partner; profiles/r02).  Here the first layer is
-                // produced one 32-feature tile (two k-slabs) at a time and the 24 MFMAs that consume tile k are issued one by
-                // one BETWEEN the three VALU chunks of each element pair of tile k+1; sched_barrier after every chunk pins the
-                // order.  Fragments are double-buffered (2 x 16 registers), W2' fragments and P/Q rows arrive one group ahead.
+                // produced one 16-feature k-slab at a time and the 12 MFMAs that consume slab s are issued one by one BETWEEN
+                // the three VALU chunks of each element pair of slab s+1; sched_barrier after every chunk pins the order.
+                // Only slab 0 is produced without MFMAs beside it and only slab 7's MFMAs have no VALU beside them.
+                // Fragments are double-buffered (2 x 8 registers), W2' fragments and P/Q rows arrive one group ahead.
                 const float xv = (hh ? d0 : r) * sX;
                 const float xh_ = __uint_as_float(__float_as_uint(xv) & 0xffffe000u);
                 const uint4 xf = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xh_, xh_)),
                                             __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xv - xh_, 0.0f)), 0u, 0u);
                 const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane + opq;
                 floatx16 c2[4] = {splat16(0.0f), splat16(0.0f), splat16(0.0f), splat16(0.0f)};
-                uint4 fh[2][2], fl[2][2];          // [buffer][slab of the tile]: B fragments hi / lo
+                uint4 fh[2], fl[2];                // [slab parity]: B fragments hi / lo of one 16-feature k-slab
                 float4 Pq[2], Qq[2];               // P / Q rows of one quad (8 features of this half), double-buffered
                 uint4 af[2][4];                    // W2' fragments of one (slab, output half): ah0, ah1, al0, al1
                 floatx16 g1;                       // geometric term of the tile in production
                 float yy[2], ee[2], uu[2];         // element pair in flight through the three chunks
 
-                auto load_pq = [&](int mt, int qd, int buf) {
-                    Pq[buf] = *reinterpret_cast<const float4*>(Pp + 32 * mt + 8 * qd);
-                    Qq[buf] = *reinterpret_cast<const float4*>(Qp + 32 * mt + 8 * qd);
+                // quad gq = 4 * tile + quad of the tile (8 features of this lane half)
+                auto load_pq = [&](int gq) {
+                    Pq[gq & 1] = *reinterpret_cast<const float4*>(Pp + 8 * gq);
+                    Qq[gq & 1] = *reinterpret_cast<const float4*>(Qp + 8 * gq);
                 };
                 // (DL_KO_*: knock-out switches of the energy / timing experiments under profiles/; never set in the product build)
-                auto load_a = [&](int slab, int oh, int buf) {
+                auto load_a = [&](int slab, int oh) {
+                    const int buf = oh;
 #ifdef DL_KO_WREAD
-                    af[buf][0] = fh[0][0]; af[buf][1] = fl[0][0]; af[buf][2] = fh[0][1]; af[buf][3] = fl[0][1];
+                    af[buf][0] = fh[0]; af[buf][1] = fl[0]; af[buf][2] = fh[1]; af[buf][3] = fl[1];
 #else
                     af[buf][0] = Wq[(slab * 4 + 2 * oh) * 64]; af[buf][1] = Wq[(slab * 4 + 2 * oh + 1) * 64];
                     af[buf][2] = Wq[((8 + slab) * 4 + 2 * oh) * 64]; af[buf][3] = Wq[((8 + slab) * 4 + 2 * oh + 1) * 64];
 #endif
                 };
-                // the three VALU chunks of element pair e (registers 2e, 2e+1) of the tile in production
-                auto chunk_a = [&](int e) {
-                    const float4 P = Pq[(e >> 1) & 1], Q = Qq[(e >> 1) & 1];
+                // the three VALU chunks of element pair ge = 8 * tile + e (registers 2e, 2e+1 of the tile's accumulator)
+                auto chunk_a = [&](int ge) {
+                    const int e = ge & 7, gq = ge >> 1;
+                    const float4 P = Pq[gq & 1], Q = Qq[gq & 1];
                     const float p0 = (e & 1) ? P.z + Q.z : P.x + Q.x, p1 = (e & 1) ? P.w + Q.w : P.y + Q.y;
                     yy[0] = fmaf(g1[2 * e], invS1, p0); yy[1] = fmaf(g1[2 * e + 1], invS1, p1);
 #ifdef DL_KO_TRANS
@@ -569,7 +572,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     ee[0] = __builtin_amdgcn_rcpf(fmaf(ee[0], isa, isa)); ee[1] = __builtin_amdgcn_rcpf(fmaf(ee[1], isa, isa));
 #endif
                 };
-                auto chunk_c = [&](int e, int buf) {
+                auto chunk_c = [&](int ge) {
                     uu[0] = yy[0] * ee[0]; uu[1] = yy[1] * ee[1];
 #ifdef DL_KO_SPLIT
                     const unsigned hp = __float_as_uint(uu[0]) & 0x3bff3bffu, lp = __float_as_uint(uu[1]) & 0x3bff3bffu;
@@ -579,17 +582,17 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
                     const unsigned lp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(uu[0] - h0, uu[1] - h1));
 #endif
-                    const int sl = e >> 2, d = e & 3;           // slab of the tile, dword of the fragment
-                    if (d == 0) { fh[buf][sl].x = hp; fl[buf][sl].x = lp; }
-                    if (d == 1) { fh[buf][sl].y = hp; fl[buf][sl].y = lp; }
-                    if (d == 2) { fh[buf][sl].z = hp; fl[buf][sl].z = lp; }
-                    if (d == 3) { fh[buf][sl].w = hp; fl[buf][sl].w = lp; }
+                    const int buf = (ge >> 2) & 1, d = ge & 3;      // slab parity, dword of the fragment
+                    if (d == 0) { fh[buf].x = hp; fl[buf].x = lp; }
+                    if (d == 1) { fh[buf].y = hp; fl[buf].y = lp; }
+                    if (d == 2) { fh[buf].z = hp; fl[buf].z = lp; }
+                    if (d == 3) { fh[buf].w = hp; fl[buf].w = lp; }
                 };
-                // MFMA number i (0..23) of the stage that consumes tile k: group = (slab, output half), six per group
-                auto mfma_i = [&](int k, int i) {
-                    const int grp = i / 6, m6 = i % 6, sl = grp >> 1, oh = grp & 1, buf = grp & 1;
-                    const uint4& a = af[buf][(m6 < 2 ? 2 : 0) + (m6 & 1)];          // lo, lo, hi, hi, hi, hi
-                    const uint4& b = (m6 == 2 || m6 == 3) ? fl[k & 1][sl] : fh[k & 1][sl];
+                // MFMA number i (0..11) of the stage that consumes k-slab s: group = output half, six per group
+                auto mfma_i = [&](int s, int i) {
+                    const int oh = i / 6, m6 = i % 6;
+                    const uint4& a = af[oh][(m6 < 2 ? 2 : 0) + (m6 & 1)];          // lo, lo, hi, hi, hi, hi
+                    const uint4& b = (m6 == 2 || m6 == 3) ? fl[s & 1] : fh[s & 1];
 #ifdef DL_KO_MFMA2
                     c2[2 * oh + (m6 & 1)][i & 15] += __uint_as_float((a.x ^ b.y) & 0x3fffffffu);
 #else
@@ -597,39 +600,39 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 #endif
                 };
 
-                // prologue: tile 0 of the first layer (no MFMAs to hide under yet), first W2' group, first rows
-                load_pq(0, 0, 0);
+                // prologue: k-slab 0 of the first layer (no MFMAs to hide under yet), first W2' group, first rows
+                load_pq(0);
                 g1 = mfma_h(gaf[0], xf, splat16(0.0f));
-                load_a(0, 0, 0);
+                load_a(0, 0);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if ((e & 1) == 0 && e < 6) load_pq(0, (e >> 1) + 1, ((e >> 1) + 1) & 1);
-                    chunk_a(e); chunk_b(); chunk_c(e, 0);
+                for (int ge = 0; ge < 4; ++ge) {
+                    if ((ge & 1) == 0) load_pq((ge >> 1) + 1);
+                    chunk_a(ge); chunk_b(); chunk_c(ge);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // stage k: the 24 MFMAs of tile k, tile k+1 of the first layer in their shadow
-                    if (k < 3) { g1 = mfma_h(gaf[k + 1], xf, splat16(0.0f)); load_pq(k + 1, 0, 0); }
+                for (int s = 0; s < 8; ++s) {
+                    // stage s: the 12 MFMAs of k-slab s, k-slab s+1 of the first layer in their shadow (one chunk per MFMA)
 #pragma unroll
-                    for (int i = 0; i < 24; ++i) {
-                        const int grp = i / 6, m6 = i % 6, e = i / 3, ph = i % 3;
-                        // W2' fragments of the next group (of the next stage after the last group) one group ahead
+                    for (int i = 0; i < 12; ++i) {
+                        const int m6 = i % 6, ge = 4 * (s + 1) + i / 3, ph = i % 3;
+                        // W2' fragments of the next group one group ahead
                         if (m6 == 0) {
-                            const int ng = grp + 1;
-                            if (ng < 4) load_a(2 * k + (ng >> 1), ng & 1, ng & 1);
-                            else if (k < 3) load_a(2 * (k + 1), 0, 0);
+                            const int ng = 2 * s + i / 6 + 1;
+                            if (ng < 16) load_a(ng >> 1, ng & 1);
                         }
-                        mfma_i(k, i);
-                        if (k < 3) {
-                            if (ph == 0) { if ((e & 1) == 0 && e < 6) load_pq(k + 1, (e >> 1) + 1, ((e >> 1) + 1) & 1); chunk_a(e); }
+                        mfma_i(s, i);
+                        // the slab after the next opens a tile: its geometric term (g1's last element was read at i = 9)
+                        if (i == 10 && s < 6 && !(s & 1)) g1 = mfma_h(gaf[(s + 2) >> 1], xf, splat16(0.0f));
+                        if (s < 7) {
+                            if (ph == 0) { if ((ge & 1) == 0 && (ge >> 1) + 1 < 16) load_pq((ge >> 1) + 1); chunk_a(ge); }
                             if (ph == 1) chunk_b();
-                            if (ph == 2) chunk_c(e, (k + 1) & 1);
+                            if (ph == 2) chunk_c(ge);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                const float m = float(m_raw);
+                const float m = ok ? float(m_raw) : 0.0f;
                 TileVecs tv0 = load_vecs(0);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
