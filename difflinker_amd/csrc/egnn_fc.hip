@@ -284,6 +284,13 @@ __device__ __forceinline__ float node_pre(const Lds& v, int nb, int w, int lane,
 // f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
 constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, FM_X02 = 6;
 
+// f16x3: common scale S1 of the rank-2 geometric term (r * wr' and d0 * wd' products in one accumulator); sc[6], sc[7] =
+// max |wr'|, max |wd'|.  The sender rows Q are stored times S1 (node_pre) and enter that MFMA as its C operand.
+__device__ __forceinline__ float geo_scale(const Lds& v, const float* __restrict__ sc) {
+    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+    return fminf(scale_for(4.0f * x2) * scale_for(sc[6]), scale_for(4.0f * x02) * scale_for(sc[7]));
+}
+
 // One pass over all n_b^2 ordered pairs of the molecule, "receiver-stationary":
 //   * the 256 lane pairs (c, c+32) of the 8 waves are SLOTS; atom i owns g = min(256 / n_b, n_b) consecutive slots and
 //     slot (i, chunk) walks the senders j = chunk*q + t, t = 0 .. q-1, q = ceil(n_b / g): one MFMA column per slot, the
@@ -368,9 +375,8 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) ga[mt] = v.vec[(hh ? HID : 0) + 32 * mt + c];
         } else {
-            const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
             const float s_wr = scale_for(sc[6]), s_wd = scale_for(sc[7]);
-            const float S1 = fminf(scale_for(4.0f * x2) * s_wr, scale_for(4.0f * x02) * s_wd);
+            const float S1 = geo_scale(v, sc);
             invS1 = inv_pow2(S1);
             sX = S1 * inv_pow2(hh ? s_wd : s_wr);
             const float s_w = hh ? s_wd : s_wr;
@@ -436,6 +442,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             };
             // SiLU + mask + sum over senders (GCL) / w7' dot (coordinate head) of one 32-feature tile of D2
             auto epilogue = [&](floatx16& c2, int mt, const TileVecs& tv, float m) {
+                const float im = (m != 0.0f) ? __builtin_amdgcn_rcpf(m) : 1.2676506e30f;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
                     const float bb[4] = {tv.b[qq].x, tv.b[qq].y, tv.b[qq].z, tv.b[qq].w};
@@ -445,6 +452,12 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     for (int k = 0; k < 4; ++k) {
                         const int reg = 4 * qq + k;
                         const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
+                        if (PREC == 1 && !EQUIV && !ATT) {
+                            // m * y2 / (1 + 2^y2) with the multiplier inside the reciprocal: im = 1 / m (collate's edge_mask holds
+                            // -1 and, on the diagonal, -2: exact), 2^100 for m = 0 (the term is < 2^-100 |y2|: nothing in fp32 sums)
+                            agg[mt][reg] = fmaf(y2, __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(y2), im, im)), agg[mt][reg]);
+                            continue;
+                        }
 #if defined(DL_KO_TRANS)
                         const float u2 = y2 * fmaf(y2, 0.25f, 0.5f);
 #else
@@ -532,15 +545,17 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 const uint4* Wq = reinterpret_cast<const uint4*>(v.W) + lane + opq;
                 floatx16 c2[4] = {splat16(0.0f), splat16(0.0f), splat16(0.0f), splat16(0.0f)};
                 uint4 fh[2], fl[2];                // [slab parity]: B fragments hi / lo of one 16-feature k-slab
-                float4 Pq[2], Qq[2];               // P / Q rows of one quad (8 features of this half), double-buffered
+                float4 Pq[2];                      // P row of one quad (8 features of this half), double-buffered
+                floatx16 Qc;                       // Q row (times S1) of the 32-feature tile whose geometric MFMA is next
                 uint4 af[2][4];                    // W2' fragments of one (slab, output half): ah0, ah1, al0, al1
                 floatx16 g1;                       // geometric term of the tile in production
                 float yy[2], ee[2], uu[2];         // element pair in flight through the three chunks
 
                 // quad gq = 4 * tile + quad of the tile (8 features of this lane half)
-                auto load_pq = [&](int gq) {
-                    Pq[gq & 1] = *reinterpret_cast<const float4*>(Pp + 8 * gq);
-                    Qq[gq & 1] = *reinterpret_cast<const float4*>(Qp + 8 * gq);
+                auto load_pq = [&](int gq) { Pq[gq & 1] = *reinterpret_cast<const float4*>(Pp + 8 * gq); };
+                auto load_qc = [&](int mt, int qq) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(Qp + 32 * mt + 8 * qq);
+                    Qc[4 * qq] = t4.x; Qc[4 * qq + 1] = t4.y; Qc[4 * qq + 2] = t4.z; Qc[4 * qq + 3] = t4.w;
                 };
                 // (DL_KO_*: knock-out switches of the energy / timing experiments under profiles/; never set in the product build)
                 auto load_a = [&](int slab, int oh) {
@@ -555,8 +570,8 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 // the three VALU chunks of element pair ge = 8 * tile + e (registers 2e, 2e+1 of the tile's accumulator)
                 auto chunk_a = [&](int ge) {
                     const int e = ge & 7, gq = ge >> 1;
-                    const float4 P = Pq[gq & 1], Q = Qq[gq & 1];
-                    const float p0 = (e & 1) ? P.z + Q.z : P.x + Q.x, p1 = (e & 1) ? P.w + Q.w : P.y + Q.y;
+                    const float4 P = Pq[gq & 1];
+                    const float p0 = (e & 1) ? P.z : P.x, p1 = (e & 1) ? P.w : P.y;
                     yy[0] = fmaf(g1[2 * e], invS1, p0); yy[1] = fmaf(g1[2 * e + 1], invS1, p1);
 #ifdef DL_KO_TRANS
                     ee[0] = yy[0] * 0.25f; ee[1] = yy[1] * 0.25f;
@@ -602,7 +617,9 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 
                 // prologue: k-slab 0 of the first layer (no MFMAs to hide under yet), first W2' group, first rows
                 load_pq(0);
-                g1 = mfma_h(gaf[0], xf, splat16(0.0f));
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) load_qc(0, qq);
+                g1 = mfma_h(gaf[0], xf, Qc);
                 load_a(0, 0);
 #pragma unroll
                 for (int ge = 0; ge < 4; ++ge) {
@@ -623,7 +640,9 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                         }
                         mfma_i(s, i);
                         // the slab after the next opens a tile: its geometric term (g1's last element was read at i = 9)
-                        if (i == 10 && s < 6 && !(s & 1)) g1 = mfma_h(gaf[(s + 2) >> 1], xf, splat16(0.0f));
+                        // (its Q row was requested under the first four MFMAs of this stage)
+                        if (i < 4 && s < 6 && !(s & 1)) load_qc((s + 2) >> 1, i);
+                        if (i == 10 && s < 6 && !(s & 1)) g1 = mfma_h(gaf[(s + 2) >> 1], xf, Qc);
                         if (s < 7) {
                             if (ph == 0) { if ((ge & 1) == 0 && (ge >> 1) + 1 < 16) load_pq((ge >> 1) + 1); chunk_a(ge); }
                             if (ph == 1) chunk_b();
@@ -633,15 +652,14 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     }
                 }
                 const float m = ok ? float(m_raw) : 0.0f;
-                TileVecs tv0 = load_vecs(0);
+                TileVecs tv[2];                                 // two named buffers: no register copies between tiles
+                tv[0] = load_vecs(0);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    keep_vecs(tv0);
-                    TileVecs tv1;
-                    if (mt < 3) tv1 = load_vecs(mt + 1);       // lands under this tile's epilogue
+                    keep_vecs(tv[mt & 1]);
+                    if (mt < 3) tv[(mt + 1) & 1] = load_vecs(mt + 1);       // lands under this tile's epilogue
                     __builtin_amdgcn_sched_barrier(0);
-                    epilogue(c2[mt], mt, tv0, m);
-                    if (mt < 3) tv0 = tv1;
+                    epilogue(c2[mt], mt, tv[mt & 1], m);
                 }
                 if (ATT) attend(c2, m);
             }
@@ -746,9 +764,10 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     s_h = (PREC == 1) ? scale_for(__uint_as_float(__builtin_amdgcn_readfirstlane(v.fmax[FM_H0 + par]))) : 1.0f;
     {
         // first-layer projections P,Q (fragments prefetched: `pw`; the W2' image is arriving by DMA)
-        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
+        const float S1 = (PREC == 1 && w >= 4) ? geo_scale(v, sc) : 1.0f;        // sender rows: times S1 (see geo_scale)
+        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) * S1 : 1.0f;
         const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
-        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
+        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax * inv_pow2(S1), lane);
     }
     prof_event(pf, w, lane, 11);
     dma_wait();
@@ -858,9 +877,10 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     prof_event(pf, w, lane, 30);
     {
         const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
-        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) : 1.0f;
+        const float S1 = (PREC == 1 && w >= 4) ? geo_scale(v, sc) : 1.0f;
+        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) * S1 : 1.0f;
         const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
-        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax, lane);
+        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax * inv_pow2(S1), lane);
     }
     prof_event(pf, w, lane, 31);
     dma_wait();
