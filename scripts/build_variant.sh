@@ -1,0 +1,18 @@
+#!/bin/bash
+# A/B builds of the HIP library: scripts/build_variant.sh NAME [extra hipcc flags]  ->  build/lib_NAME.so
+# (select it with DIFFLINKER_HIP_LIB=build/lib_NAME.so; build/ travels to the GPU box with the snapshot)
+set -e
+cd "$(dirname "$0")/.."
+name=$1; shift
+mkdir -p build/obj_$name
+objs=""
+for f in egnn_fc egnn_sparse size_gnn; do
+  extra=""; [ $f = egnn_fc ] && extra="-mllvm -amdgpu-sched-strategy=iterative-ilp"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -I include $extra "$@" \
+      -c difflinker_amd/csrc/$f.hip -o build/obj_$name/$f.o &
+  objs="$objs build/obj_$name/$f.o"
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o build/lib_$name.so
+rm -rf build/obj_$name
+ls -la build/lib_$name.so
