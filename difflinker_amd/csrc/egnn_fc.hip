@@ -58,7 +58,7 @@ constexpr int L_LM = L_Z + NMAX * DMAX;               // linker mask [n]
 constexpr int L_FRAG = L_LM + 56;                     // fragment mask [n]
 constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padded position [n] (int)
 constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
-constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits
+constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits, [2..11] team block (TM_*)
 constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
 constexpr int L_TOTAL = L_DUMMY + LDH;
@@ -66,6 +66,14 @@ constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
               (L_X0 % 4) == 0 && (L_AGGX % 4) == 0 && (L_Z % 4) == 0 && (L_CTX % 4) == 0, "16-byte alignment");
+
+// Team kernels (several workgroups share one molecule, see team_sync): words of v.misc.  Everything a team member needs
+// is re-read from here at the point of use, so nothing of it lives in registers across the pair loops.
+constexpr int TM_EPOCH = 2;      // exchanges completed so far
+constexpr int TM_FAIL = 3;       // a team-mate did not show up in time
+constexpr int TM_ROWS = 4;       // exchange rows of this molecule (device pointer: lo, hi)
+constexpr int TM_FLAGS = 6;      // arrival words of this molecule's workgroups (device pointer: lo, hi)
+constexpr int TM_S = 8, TM_RANK = 9, TM_R0 = 10, TM_NREC = 11;   // team size, own index, own receivers [r0, r0 + nrec)
 
 struct Lds {
     float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag, *ctx;
@@ -314,9 +322,10 @@ static_assert(NSLOT * PB_STRIDE <= L_W + UNIT, "partial-sum buffer must fit the 
 struct SlotPlan {
     int g, q;
 };
-__device__ __forceinline__ SlotPlan slot_plan(int nb) {
+// nrec receivers share the 256 slots (all n_b atoms of the molecule, or this workgroup's part of them in a team)
+__device__ __forceinline__ SlotPlan slot_plan(int nrec, int nb) {
     SlotPlan sp;
-    sp.g = min(NSLOT / nb, nb);
+    sp.g = min(NSLOT / max(nrec, 1), nb);
     sp.q = (nb + sp.g - 1) / sp.g;
     return sp;
 }
@@ -338,19 +347,22 @@ __device__ __forceinline__ void split8t(const float (&u)[8], uint4& hi, uint4& l
 
 // ATT (GCL only): edge attention m_ij *= sigmoid(w_att . m_ij + b_att) (egnn.py:52-54); `head` = b_att.
 // EQUIV: `head` = coords_range when the coordinate head goes through tanh (egnn.py:104-105), 0 otherwise.
-template <bool EQUIV, int PREC, bool ATT>
+template <bool EQUIV, int PREC, bool ATT, bool TEAM>
 __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane, const int8_t* __restrict__ emask, int N,
                                            float norm_constant, float sa, float inv_scale, const float* __restrict__ sc,
                                            float head, Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
-    const SlotPlan pl = slot_plan(nb);
+    int r0 = 0, nrec = nb;                                        // receivers of this workgroup: all, or its share of a team's
+    if constexpr (TEAM) { r0 = v.misc[TM_R0]; nrec = v.misc[TM_NREC]; }
+    const SlotPlan pl = slot_plan(nrec, nb);
     const int q = pl.q;
     const int slot = 32 * w + c;
-    const bool slot_ok = slot < nb * pl.g;
-    const int i = slot_ok ? slot / pl.g : 0;
-    const int j0 = slot_ok ? (slot - i * pl.g) * q : 0;
+    const bool slot_ok = slot < nrec * pl.g;
+    const int il = slot_ok ? slot / pl.g : 0;
+    const int i = r0 + il;
+    const int j0 = slot_ok ? (slot - il * pl.g) * q : 0;
     const int jn = slot_ok ? min(q, nb - j0) : 0;                 // senders this slot really has (may be <= 0)
-    const bool wave_active = 32 * w < nb * pl.g;                  // wave-uniform
+    const bool wave_active = 32 * w < nrec * pl.g;                // wave-uniform
     float* pb = v.A + slot * PB_STRIDE;
 
     floatx16 agg[4];
@@ -699,7 +711,7 @@ struct AggRegs {
     float4 v[4];
 };
 __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out, float scale) {
-    const SlotPlan pl = slot_plan(nb);
+    const SlotPlan pl = slot_plan(nb, nb);
     float am = 0.0f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -727,7 +739,7 @@ __device__ __forceinline__ void pair_store_gcl(const Lds& v, int nb, int tid, co
 }
 // coordinate head: aggx[i][0..2] = sum of the slot triples
 __device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid, float scale) {
-    const SlotPlan pl = slot_plan(nb);
+    const SlotPlan pl = slot_plan(nb, nb);
     if (tid < nb) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int ch = 0; ch < pl.g; ++ch) {
@@ -739,6 +751,121 @@ __device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid,
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Teams: S workgroups (S compute units) share one molecule when the batch is smaller than the chip.  Every member keeps the
+// whole molecule in its LDS and repeats the per-atom phases (projections, node MLP, sampler algebra: identical code on
+// identical data, so the copies stay bitwise equal); the O(n^2) pair loop - three quarters of a forward - is split by
+// RECEIVER: member r owns atoms [n r / S, n (r+1) / S), spreads them over all 256 slots (S times fewer senders per slot,
+// i.e. S times fewer steps) and ends up with the message sums of its atoms only.  Those rows are exchanged once per pass
+// through a small HBM buffer:  write-through (sc1) 16-byte stores -> every storing wave drains -> workgroup barrier -> one
+// lane publishes the exchange number in its arrival word (agent-scope relaxed store) -> one wave polls the S arrival words
+// (relaxed, bounded) -> workgroup barrier -> sc1 loads of ALL rows (the member's own included, so every copy continues from
+// the same bits).  Placement-independent: nothing assumes which XCD a member runs on (MI355X_MICROARCH.md, inter-workgroup
+// visibility).  Two row buffers alternate: a member can be at most one exchange ahead of the slowest one.
+// The launch must keep all S * B workgroups resident at once (one per compute unit): dl_* checks it against the CU count.
+constexpr int TEAM_MAX = 8;                                   // arrival words per molecule
+constexpr int TEAM_ROW_BYTES = NMAX * HID * 4;                // one parity of a molecule's exchange rows
+constexpr unsigned TEAM_SPIN_LIMIT = 1u << 22;                // polls (~ seconds) before a member gives up
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned long long team_ptr(const Lds& v, int word) {
+    const unsigned lo = unsigned(__builtin_amdgcn_readfirstlane(v.misc[word]));
+    const unsigned hi = unsigned(__builtin_amdgcn_readfirstlane(v.misc[word + 1]));
+    return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t team_rows(const Lds& v) {
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(team_ptr(v, TM_ROWS)), 0, 2 * TEAM_ROW_BYTES, 0x00020000);
+}
+
+// the rows of exchange number `epoch` are stored: publish, wait for the team.  On a timeout the forward goes on with
+// whatever the buffer holds and ends with flag bit 3 (later exchanges do not wait again).
+__device__ __forceinline__ void team_sync(const Lds& v, int tid, unsigned epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through stores have left
+    __syncthreads();
+    if (tid < 64) {
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        gu32* flags = reinterpret_cast<gu32*>(team_ptr(v, TM_FLAGS));
+        const int S = v.misc[TM_S], rank = v.misc[TM_RANK];
+        const unsigned target = epoch + 1u;
+        if (tid == 0) __hip_atomic_store(flags + rank, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        if (v.misc[TM_FAIL] == 0) {
+            ok = false;
+            for (unsigned spins = 0; spins < TEAM_SPIN_LIMIT; ++spins) {
+                unsigned f = target;
+                if (tid < S) f = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(int(f - target) >= 0)) { ok = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        if (tid == 0) {
+            v.misc[TM_EPOCH] = int(target);
+            if (!ok) v.misc[TM_FAIL] = 1;
+        }
+    }
+    __syncthreads();
+}
+
+// GCL: sums of the slot partials of the own receivers (chunks ascending) -> exchange -> every aggregate row in v.C; max |agg|
+__device__ __forceinline__ float team_exchange_gcl(const Lds& v, int nb, int tid, float scale) {
+    const int r0 = v.misc[TM_R0], nrec = v.misc[TM_NREC];
+    const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
+    const SlotPlan pl = slot_plan(nrec, nb);
+    const __amdgpu_buffer_rsrc_t rows = team_rows(v);
+    const int pbase = int(epoch & 1u) * TEAM_ROW_BYTES;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + THREADS * k;
+        if (e < nrec * 32) {
+            const float* src = v.A + (e >> 5) * pl.g * PB_STRIDE + 4 * (e & 31);
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int ch = 0; ch < pl.g; ++ch) {
+                const float4 p = *reinterpret_cast<const float4*>(src + ch * PB_STRIDE);
+                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+            }
+            const u32x4 bits = {__float_as_uint(s.x * scale), __float_as_uint(s.y * scale), __float_as_uint(s.z * scale),
+                                __float_as_uint(s.w * scale)};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + ((r0 + (e >> 5)) * HID + 4 * (e & 31)) * 4, 0, 16);  // aux 16: sc1
+        }
+    }
+    team_sync(v, tid, epoch);              // (its first barrier also ends every read of the partial rows: P, Q, H, W2' are free)
+    float am = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + THREADS * k;
+        if (e < nb * 32) {
+            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + ((e >> 5) * HID + 4 * (e & 31)) * 4, 0, 16);
+            const float4 a = make_float4(__uint_as_float(bits.x), __uint_as_float(bits.y), __uint_as_float(bits.z), __uint_as_float(bits.w));
+            *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = a;
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
+        }
+    }
+    return am;
+}
+// coordinate head: the triples of the own receivers -> exchange -> v.aggx of every atom
+__device__ __forceinline__ void team_exchange_equiv(const Lds& v, int nb, int tid, float scale) {
+    const int r0 = v.misc[TM_R0], nrec = v.misc[TM_NREC];
+    const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
+    const SlotPlan pl = slot_plan(nrec, nb);
+    const __amdgpu_buffer_rsrc_t rows = team_rows(v);
+    const int pbase = int(epoch & 1u) * TEAM_ROW_BYTES;
+    if (tid < nrec) {
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int ch = 0; ch < pl.g; ++ch) {
+            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (tid * pl.g + ch));
+            sx += p.x; sy += p.y; sz += p.z;
+        }
+        const u32x4 bits = {__float_as_uint(sx * scale), __float_as_uint(sy * scale), __float_as_uint(sz * scale), 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + (r0 + tid) * HID * 4, 0, 16);
+    }
+    team_sync(v, tid, epoch);
+    if (tid < nb) {
+        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + tid * HID * 4, 0, 16);
+        v.aggx[4 * tid + 0] = __uint_as_float(bits.x); v.aggx[4 * tid + 1] = __uint_as_float(bits.y);
+        v.aggx[4 * tid + 2] = __uint_as_float(bits.z);
+    }
+}
 
 // scale of the edge-pass A-fragments: |u| <= |y| <= |P|+|Q| + r*|wr'| + d0*|wd'|,  r <= 4 max|x|^2
 __device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restrict__ sc) {
@@ -749,7 +876,7 @@ __device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restr
 
 // GCL (egnn.py:45-80) on the LDS-resident molecule; `hown` is this wave's 32x32 tile of h in registers.
 // `par` (f16x3): which of the two h-magnitude slots is current; toggled when h is rewritten.
-template <int PREC>
+template <int PREC, bool TEAM>
 __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __restrict__ g,
                                          floatx16& hown, const int8_t* __restrict__ emask, int N, Prof& pf, int& par,
                                          PreW& pw, const NextPass nx, const ModelDims& md) {
@@ -776,8 +903,8 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
     // ends with the partial rows in LDS
-    if (md.attention) pair_phase<false, PREC, true>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, sc[8], pf);
-    else pair_phase<false, PREC, false>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
+    if (md.attention) pair_phase<false, PREC, true, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, sc[8], pf);
+    else pair_phase<false, PREC, false, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
     prof_event(pf, w, lane, 13);
     }
     // ---- back: aggregate completion + node MLP (lane indices re-derived, see lane_ids)
@@ -785,7 +912,12 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
     const bool active = (mt == 0) || (nb > 32);
     lds_barrier();                         // partial rows complete
-    {
+    if constexpr (TEAM) {
+        const float am = team_exchange_gcl(v, nb, tid, md.mean ? 1.0f / float(N) : 1.0f);    // every aggregate row -> v.C
+        stage_next(v, nx, w, tid);
+        if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
+        if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
+    } else {
         AggRegs ar;
         const float am = pair_reduce_gcl(v, nb, tid, ar, md.mean ? 1.0f / float(N) : 1.0f);
         lds_barrier();                     // every partial read: P, Q, H, W2' regions are free
@@ -865,7 +997,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
 }
 
 // EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
-template <int PREC>
+template <int PREC, bool TEAM>
 __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __restrict__ e,
                                            const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf,
                                            int par, PreW& pw, const NextPass nx, const ModelDims& md) {
@@ -888,7 +1020,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
-    pair_phase<true, PREC, false>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
+    pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
                                   md.tanh ? md.coords_range : 0.0f, pf);      // ends with the partial triples in LDS
     prof_event(pf, w, lane, 33);
     }
@@ -898,8 +1030,13 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     load_next(pw, nx, w, lane);            // next block's first pass, under the reduction
     lds_barrier();                         // partial triples complete
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
-    pair_reduce_equiv(v, nb, tid, md.mean ? 1.0f / float(N) : (md.tanh ? md.inv_norm : 1.0f));
-    lds_barrier();                         // partials read: P, Q, W2' regions are free
+    const float xscale = md.mean ? 1.0f / float(N) : (md.tanh ? md.inv_norm : 1.0f);
+    if constexpr (TEAM) {
+        team_exchange_equiv(v, nb, tid, xscale);             // (barriers inside: partials read, P, Q, W2' regions are free)
+    } else {
+        pair_reduce_equiv(v, nb, tid, xscale);
+        lds_barrier();                     // partials read: P, Q, W2' regions are free
+    }
     stage_next(v, nx, w, tid);
     if (PREC == 1 && tid == 0) { v.fmax[FM_PQ] = 0u; v.fmax[FM_X2] = 0u; }
     lds_barrier();
@@ -920,7 +1057,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
 
 // Dynamics.forward for the molecule resident in LDS: reads v.z (state), v.ctx, v.lm, time feature t;
 // writes eps_hat[a][0:3+nf] into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
-template <int PREC>
+template <int PREC, bool TEAM>
 __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, const ModelDims& md,
                                                  const float* __restrict__ wp, float tfeat,
                                                  const int8_t* __restrict__ emask, int N, Prof& pf) {
@@ -1001,10 +1138,10 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
 #pragma nounroll
         for (int gi = 0; gi < 2; ++gi) {
             const NextPass nx = {base + (gi + 1) * GCL_SIZE, gi == 1};
-            gcl_pass<PREC>(v, nb, base + gi * GCL_SIZE, hown, emask, N, pf, par, pw, nx, md);
+            gcl_pass<PREC, TEAM>(v, nb, base + gi * GCL_SIZE, hown, emask, N, pf, par, pw, nx, md);
         }
         const NextPass nx = {blk + 1 < md.n_layers ? base + BLOCK_SIZE : nullptr, false};
-        equiv_pass<PREC>(v, nb, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par, pw, nx, md);
+        equiv_pass<PREC, TEAM>(v, nb, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par, pw, nx, md);
     }
     prof_event(pf, w, lane, 3);
 
@@ -1030,6 +1167,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
         eps[(tid >> 2) * DMAX + (tid & 3)] = vel;
         if (vel != vel) nanbits |= 1;
     }
+    if (TEAM && tid == 0 && v.misc[TM_FAIL] != 0) nanbits |= 8;       // a team exchange timed out: the result is void
     if (nanbits) atomicOr(&v.misc[1], nanbits);
     __syncthreads();
     prof_event(pf, w, lane, 4);
@@ -1070,29 +1208,68 @@ struct FwdArgs {
     float* out;
     int* nan_flags;
     unsigned long long* prof;
+    int team;                       // team kernels: workgroups per molecule, exchange rows [B][2][NMAX][HID], arrival words [B][TEAM_MAX]
+    float* team_rows;
+    unsigned* team_flags;
 };
 
-template <int PREC>
+// Team kernels: workgroup k -> (molecule slot, member index).  The members of a team sit 8 workgroups apart, which is the
+// same XCD under the dispatch pattern observed on this chip (workgroup k -> XCD k % 8): the exchange then stays inside one
+// L2.  Correctness does not depend on it.
+struct TeamSlot {
+    int slot, rank;
+};
+__device__ __forceinline__ TeamSlot team_slot(int k, int S) {
+    const int group = k / (8 * S), within = k - group * 8 * S;
+    TeamSlot t;
+    t.slot = group * 8 + (within & 7);
+    t.rank = within >> 3;
+    return t;
+}
+// after compact_atoms (which ends with a barrier): the team block of v.misc; visible after the next barrier
+__device__ __forceinline__ void team_init(const Lds& v, int nb, int tid, int S, int rank, float* rows, unsigned* flags) {
+    if (tid == 0) {
+        const unsigned long long pr = reinterpret_cast<unsigned long long>(rows), pf = reinterpret_cast<unsigned long long>(flags);
+        v.misc[TM_EPOCH] = 0; v.misc[TM_FAIL] = 0;
+        v.misc[TM_ROWS] = int(unsigned(pr)); v.misc[TM_ROWS + 1] = int(unsigned(pr >> 32));
+        v.misc[TM_FLAGS] = int(unsigned(pf)); v.misc[TM_FLAGS + 1] = int(unsigned(pf >> 32));
+        v.misc[TM_S] = S; v.misc[TM_RANK] = rank;
+        const int r0 = (nb * rank) / S;
+        v.misc[TM_R0] = r0; v.misc[TM_NREC] = (nb * (rank + 1)) / S - r0;
+    }
+}
+
+template <int PREC, bool TEAM>
 __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
     const int tid = threadIdx.x;
-    const int b = blockIdx.x;
+    int b = blockIdx.x, rank = 0;
+    if constexpr (TEAM) {
+        const TeamSlot ts = team_slot(blockIdx.x, p.team);
+        if (ts.slot >= p.B) return;
+        b = ts.slot; rank = ts.rank;
+    }
+    const bool writer = rank == 0;          // a team's copies are identical: its first member writes the results
     const int N = p.N, D = 3 + p.md.nf;
     const int8_t* nm = p.node_mask + size_t(b) * N;
     float* out_b = p.out + size_t(b) * N * D;
 
     const int nb = compact_atoms(v, nm, N, tid);
+    if constexpr (TEAM) team_init(v, nb, tid, p.team, rank, p.team_rows + size_t(b) * 2 * NMAX * HID, p.team_flags + size_t(b) * TEAM_MAX);
     // padded rows of the output are exactly zero (node_mask multiply, egnn.py:420,236-237)
-    for (int e = tid; e < N * D; e += THREADS)
-        if (nm[e / D] == 0) out_b[e] = 0.0f;
+    if (writer)
+        for (int e = tid; e < N * D; e += THREADS)
+            if (nm[e / D] == 0) out_b[e] = 0.0f;
     if (nb > NMAX) {
-        for (int e = tid; e < N * D; e += THREADS) out_b[e] = 0.0f;
-        if (tid == 0) p.nan_flags[b] = 4;
+        if (writer) {
+            for (int e = tid; e < N * D; e += THREADS) out_b[e] = 0.0f;
+            if (tid == 0) p.nan_flags[b] = 4;
+        }
         return;
     }
     if (nb == 0) {
-        if (tid == 0) p.nan_flags[b] = 0;
+        if (writer && tid == 0) p.nan_flags[b] = 0;
         return;
     }
     const float* xh_b = p.xh + size_t(b) * N * D;
@@ -1111,7 +1288,8 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     Prof pf;
     pf.buf = (b == 0) ? p.prof : nullptr;
     pf.n = 0;
-    forward_molecule<PREC>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf);
+    forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf);
+    if (!writer) return;
     for (int e = tid; e < nb * D; e += THREADS) {
         const int a = e / D, d = e - a * D;
         out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
@@ -1127,26 +1305,38 @@ struct ChainArgs {
     ModelDims md;
     dl_chain_args a;
     unsigned long long* prof;
+    float* team_rows;               // team kernels: exchange rows [B][2][NMAX][HID], arrival words [B][TEAM_MAX] (inside a.team_ws)
+    unsigned* team_flags;
 };
 
-template <int PREC>
+template <int PREC, bool TEAM>
 __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
     const dl_chain_args& g = p.a;
     const int tid = threadIdx.x;
-    const int b = g.order ? g.order[blockIdx.x] : int(blockIdx.x);
+    int k = blockIdx.x, rank = 0;
+    if constexpr (TEAM) {
+        const TeamSlot ts = team_slot(blockIdx.x, g.team);
+        if (ts.slot >= g.B) return;
+        k = ts.slot; rank = ts.rank;
+    }
+    const bool writer = rank == 0;          // a team's copies are identical: its first member writes the results
+    const int b = g.order ? g.order[k] : k;
     const int N = g.N, nf = p.md.nf, D = 3 + nf, T = g.T, K = g.keep_frames, B = g.B;
     const int8_t* nm = g.node_mask + size_t(b) * N;
     const size_t frame = size_t(B) * N * D;
     float* chain_b = g.chain + size_t(b) * N * D;
 
     const int nb = compact_atoms(v, nm, N, tid);
-    if (tid == 0) { g.nan_flags[b] = (nb > NMAX) ? 4 : 0; g.nan_step[b] = -1; }
-    // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
-    for (int k = 0; k < K; ++k)
-        for (int e = tid; e < N * D; e += THREADS)
-            if (nm[e / D] == 0 || nb > NMAX) chain_b[k * frame + e] = 0.0f;
+    if constexpr (TEAM) team_init(v, nb, tid, g.team, rank, p.team_rows + size_t(k) * 2 * NMAX * HID, p.team_flags + size_t(k) * TEAM_MAX);
+    if (writer) {
+        if (tid == 0) { g.nan_flags[b] = (nb > NMAX) ? 4 : 0; g.nan_step[b] = -1; }
+        // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
+        for (int kf = 0; kf < K; ++kf)
+            for (int e = tid; e < N * D; e += THREADS)
+                if (nm[e / D] == 0 || nb > NMAX) chain_b[kf * frame + e] = 0.0f;
+    }
     if (nb > NMAX || nb == 0) return;
 
     if (tid < nb) {
@@ -1180,15 +1370,15 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         Prof pf;
         pf.buf = (blockIdx.x == 0 && q == 0) ? p.prof : nullptr;
         pf.n = 0;
-        forward_molecule<PREC>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf);
+        forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf);
         if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
-            if (tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
+            if (writer && tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
             return;
         }
         const int s = T - 1 - q;
         const int widx = decode ? 0 : (s * K) / T;
         const bool last_writer = (s == 0) || (((s - 1) * K) / T != widx);
-        const bool write = !decode && last_writer && widx != 0;   // frame 0 is overwritten by the decode
+        const bool write = writer && !decode && last_writer && widx != 0;   // frame 0 is overwritten by the decode
         for (int e = tid; e < nb * D; e += THREADS) {
             const int a = e / D, d = e - a * D;
             const size_t n = size_t(b) * N + v.idx[a];
@@ -1219,7 +1409,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         }
         __syncthreads();
     }
-    if (tid < nb) {
+    if (writer && tid < nb) {
         const int a = tid;
         float* o = chain_b + v.idx[a] * D;
         o[0] = v.z[a * DMAX + 0]; o[1] = v.z[a * DMAX + 1]; o[2] = v.z[a * DMAX + 2];
@@ -1541,10 +1731,42 @@ void dl_model_destroy(dl_model* m) {
     free(m);
 }
 
-int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
-                           int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
-                           const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
-                           void* stream) {
+// ---- teams (several compute units per molecule): workspace layout and launch geometry
+static size_t team_rows_bytes(int32_t B) { return size_t(B) * 2 * TEAM_ROW_BYTES; }
+
+size_t dl_team_workspace_bytes(int32_t B) {
+    if (B <= 0) return 0;
+    return team_rows_bytes(B) + size_t(B) * TEAM_MAX * sizeof(unsigned);
+}
+
+int32_t dl_team_max(int32_t B) {
+    if (B <= 0) return 1;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
+    const int slots = (B + 7) / 8 * 8;                  // team members sit 8 workgroups apart: whole groups of 8 molecules
+    int S = 1;
+    while (S < 4 && slots * (S * 2) <= cus) S *= 2;
+    return S;
+}
+
+// validates a team request, zeroes the arrival words on `stream`; *grid = workgroups to launch
+static int32_t team_prepare(int32_t B, int32_t team, void* ws, size_t ws_bytes, hipStream_t stream, float** rows,
+                            unsigned** flags, int* grid) {
+    if (team != 2 && team != 4) return DL_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dl_team_workspace_bytes(B) || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0) return DL_ERR_BAD_ARG;
+    if (team > dl_team_max(B)) return DL_ERR_BAD_ARG;    // every workgroup of every team must be resident at once
+    *rows = static_cast<float*>(ws);
+    *flags = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + team_rows_bytes(B));
+    *grid = (B + 7) / 8 * 8 * team;
+    if (!hip_ok(hipMemsetAsync(*flags, 0, size_t(B) * TEAM_MAX * sizeof(unsigned), stream))) return DL_ERR_HIP;
+    return DL_OK;
+}
+
+int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
+                                int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
+                                const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
+                                int32_t team, void* team_ws, size_t team_ws_bytes, void* stream) {
     if (!m || !xh || !t || !node_mask || !out || !nan_flags || B < 0 || N < 1) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
     if (B == 0) return DL_OK;
@@ -1552,13 +1774,29 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float*
     a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
     a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
     a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags; a.prof = g_prof_buf;
-    if (m->cfg.precision == DL_PRECISION_F16X3)
-        hipLaunchKernelGGL(egnn_forward_fc_kernel<1>, dim3(B), dim3(THREADS), 0,
-                           static_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(egnn_forward_fc_kernel<0>, dim3(B), dim3(THREADS), 0,
-                           static_cast<hipStream_t>(stream), a);
+    a.team = 1; a.team_rows = nullptr; a.team_flags = nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
+    if (team <= 1) {
+        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, false>), dim3(B), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, false>), dim3(B), dim3(THREADS), 0, st, a);
+    } else {
+        int grid = 0;
+        const int32_t rc = team_prepare(B, team, team_ws, team_ws_bytes, st, &a.team_rows, &a.team_flags, &grid);
+        if (rc != DL_OK) return rc;
+        a.team = team;
+        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, true>), dim3(grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, true>), dim3(grid), dim3(THREADS), 0, st, a);
+    }
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+}
+
+int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
+                           int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
+                           const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
+                           void* stream) {
+    return dl_egnn_forward_fc_team(m, B, N, xh, t, t_is_scalar, node_mask, linker_mask, edge_mask, context, out, nan_flags,
+                                   1, nullptr, 0, stream);
 }
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stream) {
@@ -1567,16 +1805,24 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
         !g->coefs || !g->chain || !g->nan_flags || !g->nan_step) return DL_ERR_BAD_ARG;
     if ((g->noise_x == nullptr) != (g->noise_h == nullptr)) return DL_ERR_BAD_ARG;    // both (bank) or neither (Philox)
     if (m->cfg.context_node_nf > 0 && !g->context) return DL_ERR_BAD_ARG;
-    if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T) return DL_ERR_BAD_ARG;
+    if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T || g->team < 0) return DL_ERR_BAD_ARG;
     if (g->B == 0) return DL_OK;
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
-    if (m->cfg.precision == DL_PRECISION_F16X3)
-        hipLaunchKernelGGL(sample_chain_fc_kernel<1>, dim3(g->B), dim3(THREADS), 0,
-                           static_cast<hipStream_t>(stream), a);
-    else
-        hipLaunchKernelGGL(sample_chain_fc_kernel<0>, dim3(g->B), dim3(THREADS), 0,
-                           static_cast<hipStream_t>(stream), a);
+    a.team_rows = nullptr; a.team_flags = nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
+    if (g->team <= 1) {
+        a.a.team = 1;
+        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, false>), dim3(g->B), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, false>), dim3(g->B), dim3(THREADS), 0, st, a);
+    } else {
+        int grid = 0;
+        const int32_t rc = team_prepare(g->B, g->team, g->team_ws, g->team_ws_bytes, st, &a.team_rows, &a.team_flags, &grid);
+        if (rc != DL_OK) return rc;
+        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, true>), dim3(grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, true>), dim3(grid), dim3(THREADS), 0, st, a);
+    }
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
 

@@ -83,12 +83,15 @@ def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=N
     elif source == 'philox' or world > 1:
         kw['mol_offset'] = lo                 # counter-based draws: nothing to generate or slice, any world size
         edm.noise_source = 'philox'
-    pinned = getattr(edm, 'coef_batch', None)
+    pinned, pinned_team = getattr(edm, 'coef_batch', None), getattr(edm, 'team_batch', None)
     if pinned is None:
         edm.coef_batch = bs                  # per-step scalars of the WHOLE batch (see EDM.coef_batch)
+    if pinned_team is None:
+        edm.team_batch = bs                  # and its team size (see EDM.team_batch)
     try:
         chain = edm.sample_chain(keep_frames=keep_frames, **local, **kw)
     finally:
         edm.coef_batch = pinned
+        edm.team_batch = pinned_team
         edm.noise_source = source
     return all_gather_frames(chain, bs, group) if gather else chain

@@ -63,6 +63,10 @@ class EDM(torch.nn.Module):
         # [B,1] tensors and PyTorch's CPU kernels round differently on their vector (B >= 16) and scalar paths, so a
         # shard of a batch pins this to the size of the whole batch to sample exactly what the unsharded call would.
         self.coef_batch = None
+        # batch size the team size (compute units per molecule, Dynamics.team = 'auto') is chosen for (None: the batch at
+        # hand).  A shard of a batch pins it to the whole batch as well: the order in which an atom's messages are summed
+        # depends on the team size, so bitwise-identical samples for any split need one team size for all of them.
+        self.team_batch = None
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError('EDM.forward is the training loss (edm.py:41-124): out of scope of the '
@@ -282,16 +286,20 @@ class EDM(torch.nn.Module):
         chain = torch.zeros((keep_frames, bs, n, self.n_dims + nf), device=dev)
         flags = torch.zeros(bs, dtype=torch.int32, device=dev)
         steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+        # a batch smaller than the chip: several compute units per molecule (Dynamics.team)
+        team = self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)))
+        team_ws, team_bytes = self.dynamics.team_workspace(bs, dev) if team > 1 else (None, 0)
         args = _lib.DLChainArgs(
             B=bs, N=n, T=T, keep_frames=keep_frames,
             x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
             linker_mask=lm.data_ptr(), edge_mask=em.data_ptr() if em is not None else None,
             context=ctx.data_ptr() if ctx is not None else None,
             noise_x=None if philox else noise_x.data_ptr(), noise_h=None if philox else noise_h.data_ptr(),
-            noise_seed=seed, mol_offset=int(mol_offset), reserved=0, coefs=coefs.data_ptr(),
+            noise_seed=seed, mol_offset=int(mol_offset), team=team, coefs=coefs.data_ptr(),
             inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
             norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
-            chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr(), order=order.data_ptr())
+            chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr(), order=order.data_ptr(),
+            team_ws=team_ws.data_ptr() if team_ws is not None else None, team_ws_bytes=team_bytes)
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if getattr(self, 'profile_events', False):     # bench.py: HIP events right around the launch
@@ -327,6 +335,9 @@ class EDM(torch.nn.Module):
         the fused chain reports, per molecule, its first offending call — raise for the earliest one."""
         if bool(flags.any()):
             f, st = flags.cpu(), steps.cpu()
+            if bool((f & 8).any()):
+                raise RuntimeError('a team of workgroups did not assemble in time (another kernel held compute units): '
+                                   'sample void; retry or set Dynamics.team = 1')
             if bool((f & 4).any()):
                 raise ValueError(f'molecule with more than {_lib.load().dl_max_atoms()} real atoms: '
                                  'outside the LDS-resident fully-connected kernel')

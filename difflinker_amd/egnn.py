@@ -203,6 +203,13 @@ class Dynamics(nn.Module):
         # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'f16x3' = scaled split-fp16 on the
         # matrix cores (default, ~3e-6 rel-L2 on a 500-step chain), 'fp32' = exact fp32 MFMA.
         self.precision = os.environ.get('DIFFLINKER_PRECISION', 'f16x3')
+        # compute units per molecule on the LDS-resident path (not a reference hyper-parameter): 'auto' = as many (1, 2
+        # or 4) as keep the whole chip busy for the batch at hand - the reference's default sampling batch of 64
+        # (generate.py:145) would otherwise light a quarter of it; 1 / 2 / 4 = fixed.  Samples agree across team sizes to
+        # fp32 rounding (an atom's messages are summed in a team-size dependent order) and are bitwise repeatable for a
+        # given one: pin it when a batch must give identical bits however it is split.
+        self.team = os.environ.get('DIFFLINKER_TEAM', 'auto')
+        self._team_ws = None
 
     # ---- packed weights -----------------------------------------------------------------------------
     def _weight_version(self):
@@ -314,10 +321,12 @@ class Dynamics(nn.Module):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if not large:
-                _lib.check(lib.dl_egnn_forward_fc(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
-                                                  _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
-                                                  _lib.ptr(out), _lib.ptr(flags), ctypes.c_void_p(stream)),
-                           'dl_egnn_forward_fc')
+                team = self.team_for(bs)
+                ws, need = self.team_workspace(bs, dev) if team > 1 else (None, 0)
+                _lib.check(lib.dl_egnn_forward_fc_team(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
+                                                       _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
+                                                       _lib.ptr(out), _lib.ptr(flags), team, _lib.ptr(ws), need,
+                                                       ctypes.c_void_p(stream)), 'dl_egnn_forward_fc_team')
             else:
                 if em is None:
                     raise ValueError('molecules beyond the LDS-resident limit need the edge_mask tensor')
@@ -331,10 +340,30 @@ class Dynamics(nn.Module):
                                                         ctypes.c_void_p(stream)), 'dl_egnn_forward_fc_large')
         return out, flags
 
+    def team_for(self, batch_size):
+        """Workgroups (compute units) per molecule for a batch of ``batch_size``: ``self.team``, 'auto' = ``dl_team_max``."""
+        if self.team in ('auto', None):
+            return int(_lib.load().dl_team_max(int(batch_size)))
+        team = int(self.team)
+        if team not in (1, 2, 4):
+            raise ValueError(f'Dynamics.team must be "auto", 1, 2 or 4, not {self.team!r}')
+        return team
+
+    def team_workspace(self, batch_size, device):
+        """Exchange buffer of the team kernels (``dl_team_workspace_bytes``), cached per model."""
+        need = int(_lib.load().dl_team_workspace_bytes(int(batch_size)))
+        ws = self._team_ws
+        if ws is None or ws.numel() < need or ws.device != device:
+            ws = self._team_ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws, need
+
     def _raise_on_flags(self, flags):
         """One D2H sync per forward, like the reference's ``torch.any(torch.isnan(..))`` (egnn.py:441-442)."""
         if bool(flags.any()):
             f = flags.cpu()
+            if bool((f & 8).any()):
+                raise RuntimeError('a team of workgroups did not assemble in time (another kernel held compute units): '
+                                   'sample void; retry or set Dynamics.team = 1')
             if bool((f & 4).any()):
                 raise ValueError(f'molecule with more than {_lib.load().dl_max_atoms()} real atoms: '
                                  'outside the LDS-resident fully-connected kernel')

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 4
+#define DL_ABI_VERSION 5
 
 typedef enum dl_status {
     DL_OK = 0,
@@ -184,7 +184,7 @@ typedef struct dl_chain_args {
                                 /* both NULL: the draws are generated inside the kernel (dl_philox_fill's stream) */
     uint64_t noise_seed;        /* key of the in-kernel generator                                          */
     int32_t mol_offset;         /* global index of molecule 0 of this batch (shards of one logical batch)  */
-    int32_t reserved;
+    int32_t team;               /* compute units per molecule: 0 or 1 = one (default); 2 or 4 = a team, see below */
     const dl_step_coef* coefs;  /* device [T]       execution order (s = T-1 first)            */
     float inv_alpha0, sigma0, sigma_x;      /* final decode scalars (src/edm.py:213-216,237-242) */
     float norm_x, norm_h, bias_h;           /* norm_values[0], norm_values[1], norm_biases[1]    */
@@ -195,9 +195,28 @@ typedef struct dl_chain_args {
                                  * compute unit for the whole chain and workgroups are dispatched in index order, so a
                                  * batch larger than the chip finishes sooner when the big molecules go first
                                  * (longest-processing-time order); results are written at the molecule's own index. */
+    void* team_ws;              /* device scratch of dl_team_workspace_bytes(B) bytes, 16-byte aligned (team > 1 only) */
+    size_t team_ws_bytes;
 } dl_chain_args;
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
+
+/* Teams: a batch smaller than the chip leaves compute units idle when every molecule sits on one of them (the reference's
+ * default sampling batch is 64, generate.py:145).  With team = 2 or 4 that many workgroups share a molecule: each keeps the
+ * whole molecule in LDS and repeats the per-atom phases, the O(n^2) pair loop is split by receiving atom and the message
+ * sums are exchanged once per pass through `team_ws` (release / acquire hand-off inside the launch, placement-independent).
+ * All team * ceil(B / 8) * 8 workgroups must be resident at once: dl_team_max(B) is the largest team the current device
+ * holds for a batch of B (1, 2 or 4); a larger request returns DL_ERR_BAD_ARG.  Results agree with team = 1 to fp32
+ * rounding (the order in which an atom's messages are summed depends on the team size) and are bitwise repeatable for a
+ * given team size.  nan_flags bit 3: a team member did not show up within the spin limit (another kernel held its
+ * compute unit for seconds); the sample is void. */
+size_t dl_team_workspace_bytes(int32_t B);
+int32_t dl_team_max(int32_t B);
+/* dl_egnn_forward_fc with a team per molecule (team = 1: identical to dl_egnn_forward_fc) */
+int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
+                                int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
+                                const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
+                                int32_t team, void* team_ws, size_t team_ws_bytes, void* stream);
 
 /* One step of InpaintingEDM.sample_chain after the denoiser call (src/edm.py:568-596), or its final decode
  * (:599-610, :674-713), for one batch: the linker atoms take the p(z_s|z_t) sample, the fragment atoms are re-drawn from

@@ -8,6 +8,7 @@ ap.add_argument('--n', type=int, default=50)
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--layers', type=int, default=6)
 ap.add_argument('--precision', default='f16x3')
+ap.add_argument('--team', default='auto', help="compute units per molecule: 'auto', 1, 2 or 4")
 a = ap.parse_args()
 from difflinker_amd import Dynamics, synthetic
 from difflinker_amd.datasets import collate
@@ -17,6 +18,7 @@ inp = {k: v.to(dev) for k, v in synthetic.sampler_inputs(collate(mols)).items()}
 torch.manual_seed(0)
 dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=a.layers, norm_constant=1e-6).to(dev)
 dyn.precision = a.precision
+dyn.team = a.team if a.team == 'auto' else int(a.team)
 B, N = inp['x'].shape[:2]
 z = torch.cat([inp['x'], inp['h']], 2) * inp['fragment_mask'] + torch.randn(B, N, 12, device=dev) * inp['linker_mask']
 t = torch.full((B, 1), 0.5, device=dev)
@@ -36,4 +38,4 @@ for _ in range(20):
     dyn.forward(**args)
 ev1.record()
 torch.cuda.synchronize()
-print(f'{os.environ.get("DIFFLINKER_HIP_LIB", "product")}: forward (B={B}, n={a.n}, L={a.layers}, {a.precision}): {ev0.elapsed_time(ev1) / 20:.3f} ms')
+print(f'{os.environ.get("DIFFLINKER_HIP_LIB", "product")}: forward (B={B}, n={a.n}, L={a.layers}, {a.precision}, team {dyn.team_for(B)}): {ev0.elapsed_time(ev1) / 20:.3f} ms')

@@ -464,9 +464,9 @@ def test_geom_sized_chain_full_batch_properties():
     a = run()
     assert torch.isfinite(a).all()
     assert torch.equal(a, run()), 'bitwise repeatable'
-    edm.coef_batch = B                      # per-step scalars of the whole batch (EDM.coef_batch), as a shard would
+    edm.coef_batch = edm.team_batch = B     # per-step scalars and team size of the whole batch, as a shard would
     sub = run(slice(100, 108), mol_offset=100)
-    edm.coef_batch = None
+    edm.coef_batch = edm.team_batch = None
     assert torch.equal(sub, a[100:108]), 'independent of the rest of the batch'
     nm, fm, lm = inp['node_mask'].float(), inp['fragment_mask'], inp['linker_mask']
     assert float((a * (1 - nm)).abs().max()) == 0.0
