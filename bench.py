@@ -150,7 +150,7 @@ def secondary_measurements(device, a):
     from difflinker_amd import synthetic
     out = []
 
-    def run(tag, config, batch, precision, note):
+    def run(tag, config, batch, precision, note, team='auto'):
         data, cfg = synthetic.make_batch(config, seed=1000, batch=batch)
         cfg['precision'] = precision
         pockets = cfg['graph_type'] != 'FC'
@@ -158,6 +158,7 @@ def secondary_measurements(device, a):
         inp = {k: v.to(device) for k, v in inp_cpu.items()}
         edm = build_model(cfg, device)
         edm.noise_source = a.noise
+        edm.dynamics.team = team
         if hasattr(edm, 'last_kernel_events'):
             del edm.last_kernel_events
         torch.manual_seed(4321)
@@ -170,15 +171,17 @@ def secondary_measurements(device, a):
         t_k = (kms * 1e-3) if kms is not None else dt
         B = inp['x'].shape[0]
         out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}; {note}',
-                    'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
+                    'compute_units_per_molecule': None if pockets else edm.dynamics.team_for(B), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
                     'roofline_frac': flops / t_k / 1e12 / peak, 'roofline_peak_tflops': peak,
                     'achieved_tflops': flops / t_k / 1e12})
 
     run('c2_fp32_mode', 'C2', None, 'fp32', 'exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), same batch as the headline')
     run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph rebuilt every forward')
-    for b in (64, 257, 512):
-        run(f'c2_batch_{b}', 'C2', b, 'f16x3', 'one molecule occupies one of the 256 compute units for the whole chain; '
-            'workgroups launched biggest molecule first')
+    run('c2_batch_64_one_cu_each', 'C2', 64, 'f16x3', 'the reference\'s default sampling batch (generate.py:145), one compute unit per '
+        'molecule: a quarter of the chip', team=1)
+    for b in (64, 128, 257, 512):
+        run(f'c2_batch_{b}', 'C2', b, 'f16x3', 'Dynamics.team = auto: 4 / 2 compute units per molecule while the batch leaves the chip '
+            'room (pair loop split by receiving atom, message sums exchanged through HBM once per pass), else one, biggest first')
     return out
 
 

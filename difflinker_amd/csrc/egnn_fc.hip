@@ -1286,7 +1286,7 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     const float tfeat = p.t[size_t(b) * p.t_stride];
     const int8_t* em = p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr;
     Prof pf;
-    pf.buf = (b == 0) ? p.prof : nullptr;
+    pf.buf = (b == 0 && rank == 0) ? p.prof : nullptr;
     pf.n = 0;
     forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf);
     if (!writer) return;

@@ -210,6 +210,7 @@ class Dynamics(nn.Module):
         # given one: pin it when a batch must give identical bits however it is split.
         self.team = os.environ.get('DIFFLINKER_TEAM', 'auto')
         self._team_ws = None
+        self._team_auto = {}
 
     # ---- packed weights -----------------------------------------------------------------------------
     def _weight_version(self):
@@ -343,7 +344,10 @@ class Dynamics(nn.Module):
     def team_for(self, batch_size):
         """Workgroups (compute units) per molecule for a batch of ``batch_size``: ``self.team``, 'auto' = ``dl_team_max``."""
         if self.team in ('auto', None):
-            return int(_lib.load().dl_team_max(int(batch_size)))
+            key = int(batch_size)
+            if key not in self._team_auto:                        # a property of the device: asked once per batch size
+                self._team_auto[key] = int(_lib.load().dl_team_max(key))
+            return self._team_auto[key]
         team = int(self.team)
         if team not in (1, 2, 4):
             raise ValueError(f'Dynamics.team must be "auto", 1, 2 or 4, not {self.team!r}')

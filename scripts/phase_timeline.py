@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=50)
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--layers', type=int, default=6)
+ap.add_argument('--team', default='auto', help="compute units per molecule: 'auto', 1, 2 or 4")
 a = ap.parse_args()
 
 import subprocess
@@ -39,6 +40,7 @@ inp = synthetic.sampler_inputs(collate(mols))
 inp = {k: v.to(dev) for k, v in inp.items()}
 torch.manual_seed(0)
 dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=a.layers, norm_constant=1e-6).to(dev)
+dyn.team = a.team if a.team == 'auto' else int(a.team)
 B, N = inp['x'].shape[:2]
 z = torch.cat([inp['x'], inp['h']], 2) * inp['fragment_mask'] + torch.randn(B, N, 12, device=dev) * inp['linker_mask']
 t = torch.full((B, 1), 0.5, device=dev)
@@ -53,7 +55,7 @@ for _ in range(5):
     dyn.forward(**args)
 ev1.record()
 torch.cuda.synchronize()
-print(f'forward (B={B}, n={a.n}, L={a.layers}): {ev0.elapsed_time(ev1) / 5:.3f} ms')
+print(f'forward (B={B}, n={a.n}, L={a.layers}, team {dyn.team_for(B)}): {ev0.elapsed_time(ev1) / 5:.3f} ms')
 
 maxev = lib.dl_profile_max_events()
 assert maxev > 0, 'this library was built without -DDL_PROFILE'
