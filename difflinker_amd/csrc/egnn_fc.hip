@@ -912,6 +912,7 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
     const bool active = (mt == 0) || (nb > 32);
     lds_barrier();                         // partial rows complete
+    prof_event(pf, w, lane, 20);
     if constexpr (TEAM) {
         const float am = team_exchange_gcl(v, nb, tid, md.mean ? 1.0f / float(N) : 1.0f);    // every aggregate row -> v.C
         stage_next(v, nx, w, tid);
@@ -920,17 +921,22 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     } else {
         AggRegs ar;
         const float am = pair_reduce_gcl(v, nb, tid, ar, md.mean ? 1.0f / float(N) : 1.0f);
+        prof_event(pf, w, lane, 21);
         lds_barrier();                     // every partial read: P, Q, H, W2' regions are free
+        prof_event(pf, w, lane, 22);
         stage_next(v, nx, w, tid);         // next pass's W2' image: DMA under the node phases
         if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
         pair_store_gcl(v, nb, tid, ar);    // aggregate -> v.C
         if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
     }
+    prof_event(pf, w, lane, 23);
     {
         touch16(hown);
+        prof_event(pf, w, lane, 24);
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) store_row(v, v.A, 32 * mt + acc_row(reg, hh), nb, 32 * nt + c, hown[reg]);
     }
+    prof_event(pf, w, lane, 25);
     lds_barrier();
     prof_event(pf, w, lane, 14);
     // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
