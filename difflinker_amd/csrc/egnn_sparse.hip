@@ -6,11 +6,14 @@
 //   * node features h, the first-layer projections P,Q and the coordinates live in a caller-provided HBM
 //     workspace (L2/MALL-resident: 19 k atoms x 128 fp32 = 9.6 MB each at the C4 config);
 //   * the radius graph is rebuilt on the GPU every forward (count -> scan -> fill), one wave per atom; each
-//     atom's neighbour list is padded to whole tiles of 32 edges, so a tile belongs to ONE receiving atom;
+//     atom's neighbour list is padded to whole QUADS of 8 edge slots and the lists follow each other, so an MFMA tile
+//     (32 consecutive slots = 4 quads) holds the edges of up to four receiving atoms (padding: 5 % of the slots at
+//     the pocket configuration; whole tiles per atom cost 22 %);
 //   * the edge pass runs over tiles: first layer generated as MFMA A-fragments from gathered P_i, Q_j rows,
 //     second layer [32x128]x[128x128] on v_mfma_f32_32x32x2_f32 with the weights in LDS, SiLU, and the sum
-//     over the tile's edges reduced IN REGISTERS to one partial row per tile (no atomics: the node kernel
-//     adds an atom's tile partials in tile order, so the result is deterministic);
+//     over the edges of each quad reduced IN REGISTERS; quads of one atom inside a tile are merged, so a tile writes
+//     one partial row per receiving atom it holds (no atomics: the node kernel adds an atom's partial rows in a
+//     fixed order, so the result is deterministic);
 //   * the node MLP (+ the next pass's projections) is one kernel per pass over 32-atom row tiles.
 // Arithmetic: fp32 MFMA or the f16x3 split scheme of egnn_fc.hip (template PREC); on this path the fp16 scales are
 // local: every node-kernel workgroup scales its own 32-row tiles, every edge tile is scaled by its own max |u|.
@@ -35,8 +38,8 @@ struct PkDims {
 
 // workspace carve-up (all offsets in bytes, 256-B aligned)
 struct PkWs {
-    float *H, *P, *Q, *X, *X0, *partial, *partialx, *pmax, *qmax, *wgt;
-    int *flags, *ntile, *tile_off, *tile_row, *col, *total;
+    float *H, *P, *Q, *X, *X0, *partial, *partialx, *partialA, *partialxA, *pmax, *qmax, *wgt;
+    int *flags, *ntile, *tile_off, *tile_row, *col, *total;   // ntile / tile_off / tile_row count QUADS (8 edge slots)
     size_t bytes;
 };
 
@@ -44,7 +47,8 @@ __host__ __device__ inline size_t al256(size_t x) { return (x + 255) & ~size_t(2
 
 inline PkWs carve(void* base, int B, int N) {
     const size_t V = size_t(B) * N;
-    const size_t TMAX = V * N / 32 + V + 1;
+    const size_t QMAX = V * (N / 8 + 1) + 4;                       // quads: every atom pads its list to a multiple of 8 slots
+    const size_t TMAX = QMAX / 4 + 1;                               // MFMA tiles of 32 slots
     char* p = static_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { char* r = p ? p + off : nullptr; off += al256(bytes); return r; };
@@ -60,11 +64,15 @@ inline PkWs carve(void* base, int B, int N) {
     w.ntile = reinterpret_cast<int*>(take(V * 4));
     w.tile_off = reinterpret_cast<int*>(take((V + 1) * 4));
     w.total = reinterpret_cast<int*>(take(256));
-    w.tile_row = reinterpret_cast<int*>(take(TMAX * 4));
+    w.tile_row = reinterpret_cast<int*>(take(QMAX * 4));
     w.col = reinterpret_cast<int*>(take(TMAX * 32 * 4));
     w.wgt = reinterpret_cast<float*>(take(TMAX * 32 * 4));     // per-edge weight (graph_type 3), 0 on padding
+    // partial sums of an atom: row t of `partial` for every tile t whose FIRST quad is the atom's, row v of `partialA`
+    // for the quads from the atom's first one (when that is not the first of its tile) to the end of that tile
     w.partial = reinterpret_cast<float*>(take(TMAX * HID * 4));
     w.partialx = reinterpret_cast<float*>(take(TMAX * 16));
+    w.partialA = reinterpret_cast<float*>(take(V * HID * 4));
+    w.partialxA = reinterpret_cast<float*>(take(V * 16));
     w.bytes = off;
     return w;
 }
@@ -152,26 +160,25 @@ __global__ void pk_edges_kernel(PkDims d, PkWs w) {
         }
         const unsigned long long bal = __ballot(adj);
         if (FILL && adj) {
-            const size_t slot = size_t(base_tile) * 32 + count + __popcll(bal & ((1ull << lane) - 1ull));
+            const size_t slot = size_t(base_tile) * 8 + count + __popcll(bal & ((1ull << lane) - 1ull));
             w.col[slot] = u;
             w.wgt[slot] = wt;
         }
         count += __popcll(bal);
     }
-    const int nt = (count + 31) >> 5;
+    const int nt = (count + 7) >> 3;                                                                // quads of this atom
     if (!FILL) {
         if (lane == 0) w.ntile[v] = nt;
     } else {
-        for (int e = count + lane; e < nt * 32; e += 64) {                                         // padding
-            w.col[size_t(base_tile) * 32 + e] = -1;
-            w.wgt[size_t(base_tile) * 32 + e] = 0.0f;
+        for (int e = count + lane; e < nt * 8; e += 64) {                                           // padding
+            w.col[size_t(base_tile) * 8 + e] = -1;
+            w.wgt[size_t(base_tile) * 8 + e] = 0.0f;
         }
-        if (lane < nt) w.tile_row[base_tile + lane] = v;
-        for (int k = 64 + lane; k < nt; k += 64) w.tile_row[base_tile + k] = v;
+        for (int k = lane; k < nt; k += 64) w.tile_row[base_tile + k] = v;
     }
 }
 
-// 3. exclusive scan of ntile[0..V) -> tile_off, total tile count (single workgroup)
+// 3. exclusive scan of ntile[0..V) -> tile_off, total quad count (single workgroup)
 __global__ void pk_scan_kernel(int V, const int* __restrict__ ntile, int* __restrict__ tile_off, int* __restrict__ total) {
     __shared__ int part[1024];
     const int tid = threadIdx.x, nth = blockDim.x;
@@ -263,10 +270,16 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         if (v < d.V) {
             hv = *reinterpret_cast<const float4*>(w.H + size_t(v) * HID + 4 * q);
             if (post) {
-                const int t0 = w.tile_off[v], nt = w.ntile[v];
-                for (int k = 0; k < nt; ++k) {                      // fixed order: deterministic
-                    const float4 pv = *reinterpret_cast<const float4*>(w.partial + size_t(t0 + k) * HID + 4 * q);
-                    av.x += pv.x; av.y += pv.y; av.z += pv.z; av.w += pv.w;
+                const int q0 = w.tile_off[v], nq = w.ntile[v];      // the atom's quads
+                if (nq > 0) {                                       // fixed order: deterministic
+                    if (q0 & 3) {
+                        const float4 pv = *reinterpret_cast<const float4*>(w.partialA + size_t(v) * HID + 4 * q);
+                        av.x += pv.x; av.y += pv.y; av.z += pv.z; av.w += pv.w;
+                    }
+                    for (int t = (q0 + 3) >> 2; t <= (q0 + nq - 1) >> 2; ++t) {
+                        const float4 pv = *reinterpret_cast<const float4*>(w.partial + size_t(t) * HID + 4 * q);
+                        av.x += pv.x; av.y += pv.y; av.z += pv.z; av.w += pv.w;
+                    }
                 }
             }
         }
@@ -375,8 +388,11 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
 
 // ---------------------------------------------------------------------------------------------------
 // 6. edge kernel: persistent workgroups (4 waves, second-layer weights in LDS), waves take tiles round-robin.
-//    EQUIV = false: partial[t][f] = sum over the tile's edges of u2[f]            (edge_mask = None: weight 1)
-//    EQUIV = true : partialx[t]   = sum over the tile's edges of cdiff * (w7'.u2)
+//    A tile = 32 consecutive edge slots = 4 quads; the quads of one receiving atom inside the tile form a run.
+//    EQUIV = false: one row per run = sum over the run's edges of u2[f]            (edge_mask = None: weight 1)
+//    EQUIV = true : one triple per run = sum over the run's edges of cdiff * (w7'.u2)
+//    The run that opens the tile goes to partial[t] / partialx[t], a run that starts inside it - the first quads of its
+//    atom - to partialA[atom] / partialxA[atom].
 // ---------------------------------------------------------------------------------------------------
 template <bool EQUIV, int PREC, bool WEIGHTED>
 __global__ void __launch_bounds__(EDGE_THREADS, 2)     // two waves per SIMD (two workgroups per CU): <= 256 VGPR + AGPR
@@ -404,23 +420,32 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     const float4* wrp = reinterpret_cast<const float4*>(vec + 64 * hh);
     const float4* wdp = reinterpret_cast<const float4*>(vec + HID + 64 * hh);
     const float4* Wp = reinterpret_cast<const float4*>(W) + (64 * hh * 32 + c);
-    const int ntiles = w.total[0];
+    const int nquads = w.total[0];
+    const int ntiles = (nquads + 3) >> 2;
+    const int qg = c >> 3;                                           // quad of this lane's slot
     const int gw = blockIdx.x * (EDGE_THREADS / 64) + wv, GW = gridDim.x * (EDGE_THREADS / 64);
+    // receiving atom and sender of this lane's slot in tile tt (slots past the last quad: padding of the last atom)
+    auto tile_atoms = [&](int tt, int& ii, int& jj) {
+        const int qd = 4 * tt + qg;
+        const bool in = qd < nquads;
+        ii = w.tile_row[in ? qd : nquads - 1];
+        jj = in ? w.col[size_t(tt) * 32 + c] : -1;
+    };
 
     // Software-pipelined tile loop.  Every global access of a tile is a dependent chain (tile -> atoms -> coordinates ->
     // rows of P / Q) and the vector-memory counter retires in order, so loading at the point of use costs ~20 serialized
     // L2 round trips per tile (measured: 15 K cycles per tile against 7.4 K on the LDS-resident path).  Instead:
     //   * the geometry (i, j, r, d0, bound) of the NEXT tile is fetched while this tile computes,
     //   * this tile's 32 Q rows are requested in one burst at the top (16 x 16 B per lane, consumed slab by slab),
-    //   * the P row (one receiving atom per tile) goes through a per-wave LDS stage instead of 16 more loads per lane.
-    __shared__ __attribute__((aligned(16))) float Pst[EDGE_THREADS / 64][HID];
+    //   * the P rows (one per quad: up to four receiving atoms per tile) go through a per-wave LDS stage instead of 16 more
+    //     loads per lane.
+    __shared__ __attribute__((aligned(16))) float Pst[EDGE_THREADS / 64][4 * LDT];   // row stride LDT: the four rows fall into different banks
     float* pst = Pst[wv];
     int t = gw;
     int i = 0, jraw = -1;
     float r = 0.0f, d0 = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, pqb = 0.0f;
     if (t < ntiles) {
-        i = w.tile_row[t];
-        jraw = w.col[size_t(t) * 32 + c];
+        tile_atoms(t, i, jraw);
         const int j0 = jraw >= 0 ? jraw : i;
         const float4 xi = *reinterpret_cast<const float4*>(w.X + 4 * i);
         const float4 xj = *reinterpret_cast<const float4*>(w.X + 4 * j0);
@@ -432,11 +457,13 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         d0 = ex * ex + ey * ey + ez * ez;
         if (PREC == 1) pqb = w.pmax[i] + w.qmax[j0];
     }
-    // rows of the CURRENT tile (requested one tile ahead): the receiving atom's P row and the 32 senders' Q rows
-    float2 p2 = make_float2(0.0f, 0.0f);
+    // rows of the CURRENT tile (requested one tile ahead): the P rows of the quads' receiving atoms and the 32 senders' Q rows
+    float2 p2[4] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
     float4 qv[16];
-    auto request_rows = [&](int ii, int jj, float2& pr, float4 (&qr)[16]) {
-        pr = *reinterpret_cast<const float2*>(w.P + size_t(ii) * HID + 2 * lane);
+    auto request_rows = [&](int ii, int jj, float2 (&pr)[4], float4 (&qr)[16]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)                                  // lane 8g holds quad g's receiving atom (wave-uniform)
+            pr[g] = *reinterpret_cast<const float2*>(w.P + size_t(__builtin_amdgcn_readlane(ii, 8 * g)) * HID + 2 * lane);
         const float* Qrow = w.Q + size_t(jj) * HID;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -447,18 +474,19 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     if (t < ntiles) request_rows(i, jraw >= 0 ? jraw : i, p2, qv);
     for (; t < ntiles; t += GW) {
         const bool valid = jraw >= 0;
-        const int nvalid = __popcll(__ballot(valid)) >> 1;          // both halves hold the same 32 edges
+        const unsigned vmask = unsigned(__ballot(valid));           // both halves hold the same 32 slots; padding ends every atom's list
+        // the quads' receiving atoms (wave-uniform)
+        const int ra0 = __builtin_amdgcn_readlane(i, 0), ra1 = __builtin_amdgcn_readlane(i, 8),
+                  ra2 = __builtin_amdgcn_readlane(i, 16), ra3 = __builtin_amdgcn_readlane(i, 24);
         // ---- (1) the next tile's atoms (its rows and geometry are requested mid-body, once these have arrived)
         const int tn = t + GW;
         const bool more = tn < ntiles;
         int i_n = i, j_n = -1;
-        if (more) {
-            i_n = w.tile_row[tn];
-            j_n = w.col[size_t(tn) * 32 + c];
-        }
+        if (more) tile_atoms(tn, i_n, j_n);
         __builtin_amdgcn_sched_barrier(0);
-        *reinterpret_cast<float2*>(pst + 2 * lane) = p2;            // this tile's P row -> per-wave LDS stage
-        float2 p2n = make_float2(0.0f, 0.0f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(pst + g * LDT + 2 * lane) = p2[g];   // P rows -> per-wave LDS stage
+        float2 p2n[4];
         float4 qn[16];
         floatx16 acc0, acc1, acc2, acc3;
         float xn[12];                                              // next tile: xi, xj, yi, yj coordinates
@@ -477,7 +505,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         if constexpr (PREC == 0) {
             float a[64];
             {
-                const float4* Pp = reinterpret_cast<const float4*>(pst + 64 * hh);
+                const float4* Pp = reinterpret_cast<const float4*>(pst + qg * LDT + 64 * hh);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     const float4 P = Pp[q], Q = qv[q], wr = wrp[q], wd = wdp[q];
@@ -510,11 +538,11 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 bound = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
             }
             const float sa = scale_for(__builtin_amdgcn_readfirstlane(bound));   // wave-uniform (both halves hold the same pairs)
-            const float accs = sa * sc[sw_index], inv = inv_pow2(accs);
+            const float accs = sa * sc[sw_index], inv = inv_pow2(accs), isa = inv_pow2(sa);
             // accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
             acc0 = splat16(0.0f); acc1 = splat16(0.0f); acc2 = splat16(0.0f); acc3 = splat16(0.0f);
             const uint4* Wq = reinterpret_cast<const uint4*>(W) + lane;
-            const float* Pp = pst + 8 * hh;
+            const float* Pp = pst + qg * LDT + 8 * hh;
             const float* wrb = vec + 8 * hh;
             const float* wdb = vec + HID + 8 * hh;
 #pragma unroll
@@ -531,10 +559,10 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                     const float4 Q = qv[2 * slab + q];
                     const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
                     const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
-                    us[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x))) * sa;
-                    us[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y))) * sa;
-                    us[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z))) * sa;
-                    us[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w))) * sa;
+                    us[4 * q + 0] = silu_scaled(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)), isa);
+                    us[4 * q + 1] = silu_scaled(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)), isa);
+                    us[4 * q + 2] = silu_scaled(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)), isa);
+                    us[4 * q + 3] = silu_scaled(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)), isa);
                 }
                 uint4 ah, al;
                 split8(us, ah, al);
@@ -558,22 +586,39 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             }
         }
         if (!EQUIV) {
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            // sums over the slots of each quad: accumulator registers 4g .. 4g+3 hold the rows of quad g
+            float sq[4][4];                                         // [feature tile][quad], this lane half's rows
+            {
+                const unsigned vm = hh ? (vmask >> 4) : vmask;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                // padding edges sit at the tile's end; WEIGHTED: the int8 mask value of the edge (0 on padding)
-                const float m = WEIGHTED ? w.wgt[size_t(t) * 32 + acc_row(reg, hh)]
-                                         : ((acc_row(reg, hh) < nvalid) ? 1.0f : 0.0f);
-                s0 = fmaf(m, silu_u(acc0[reg]), s0);
-                s1 = fmaf(m, silu_u(acc1[reg]), s1);
-                s2 = fmaf(m, silu_u(acc2[reg]), s2);
-                s3 = fmaf(m, silu_u(acc3[reg]), s3);
+                for (int g = 0; g < 4; ++g) {
+                    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int reg = 4 * g + k;
+                        // WEIGHTED: the int8 mask value of the edge (0 on padding); else 1 on real edges, 0 on padding
+                        const float m = WEIGHTED ? w.wgt[size_t(t) * 32 + acc_row(reg, hh)] : float((vm >> (8 * g + k)) & 1u);
+                        s0 = fmaf(m, silu_u(acc0[reg]), s0);
+                        s1 = fmaf(m, silu_u(acc1[reg]), s1);
+                        s2 = fmaf(m, silu_u(acc2[reg]), s2);
+                        s3 = fmaf(m, silu_u(acc3[reg]), s3);
+                    }
+                    sq[0][g] = s0; sq[1][g] = s1; sq[2][g] = s2; sq[3][g] = s3;
+                }
             }
-            s0 = xor32_sum(s0); s1 = xor32_sum(s1); s2 = xor32_sum(s2); s3 = xor32_sum(s3);
-            if (hh == 0) {
-                float* dst = w.partial + size_t(t) * HID + c;
-                dst[0] = s0; dst[32] = s1; dst[64] = s2; dst[96] = s3;
-            }
+            // quads of one atom are merged from the back (wave-uniform branches); then the two lane halves of every run that
+            // remains are added and the run is written once
+            if (ra3 == ra2) { sq[0][2] += sq[0][3]; sq[1][2] += sq[1][3]; sq[2][2] += sq[2][3]; sq[3][2] += sq[3][3]; }
+            if (ra2 == ra1) { sq[0][1] += sq[0][2]; sq[1][1] += sq[1][2]; sq[2][1] += sq[2][2]; sq[3][1] += sq[3][2]; }
+            if (ra1 == ra0) { sq[0][0] += sq[0][1]; sq[1][0] += sq[1][1]; sq[2][0] += sq[2][1]; sq[3][0] += sq[3][1]; }
+            auto write_run = [&](float* row, int g) {
+                const float a0 = xor32_sum(sq[0][g]), a1 = xor32_sum(sq[1][g]), a2 = xor32_sum(sq[2][g]), a3 = xor32_sum(sq[3][g]);
+                if (hh == 0) { row[c] = a0; row[32 + c] = a1; row[64 + c] = a2; row[96 + c] = a3; }
+            };
+            write_run(w.partial + size_t(t) * HID, 0);
+            if (ra1 != ra0) write_run(w.partialA + size_t(ra1) * HID, 1);
+            if (ra2 != ra1) write_run(w.partialA + size_t(ra2) * HID, 2);
+            if (ra3 != ra2) write_run(w.partialA + size_t(ra3) * HID, 3);
         } else {
             const bool want_hi = ((c >> 2) & 1) != 0;
             const int my_reg = (c & 3) + 4 * (c >> 3);
@@ -592,10 +637,24 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             const float den = sqrtf(r + 1e-8f) + d.norm_constant;   // coord2diff, egnn.py:299-300
             float f = (hh == 0 && valid) ? s_own : 0.0f;
             if (WEIGHTED) f *= w.wgt[size_t(t) * 32 + c];
-            const float ax = half32_allsum((dx / den) * f);
-            const float ay = half32_allsum((dy / den) * f);
-            const float az = half32_allsum((dz / den) * f);
-            if (lane == 0) *reinterpret_cast<float4*>(w.partialx + size_t(t) * 4) = make_float4(ax, ay, az, 0.0f);
+            // sums over the 8 slots of each quad (lanes 8g .. 8g+7 of the first half), then the runs as above
+            const float ax8 = quad8_allsum((dx / den) * f), ay8 = quad8_allsum((dy / den) * f), az8 = quad8_allsum((dz / den) * f);
+            float qx[4], qy[4], qz[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                qx[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ax8), 8 * g));
+                qy[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ay8), 8 * g));
+                qz[g] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(az8), 8 * g));
+            }
+            if (ra3 == ra2) { qx[2] += qx[3]; qy[2] += qy[3]; qz[2] += qz[3]; }
+            if (ra2 == ra1) { qx[1] += qx[2]; qy[1] += qy[2]; qz[1] += qz[2]; }
+            if (ra1 == ra0) { qx[0] += qx[1]; qy[0] += qy[1]; qz[0] += qz[1]; }
+            if (lane == 0) {
+                *reinterpret_cast<float4*>(w.partialx + size_t(t) * 4) = make_float4(qx[0], qy[0], qz[0], 0.0f);
+                if (ra1 != ra0) *reinterpret_cast<float4*>(w.partialxA + size_t(ra1) * 4) = make_float4(qx[1], qy[1], qz[1], 0.0f);
+                if (ra2 != ra1) *reinterpret_cast<float4*>(w.partialxA + size_t(ra2) * 4) = make_float4(qx[2], qy[2], qz[2], 0.0f);
+                if (ra3 != ra2) *reinterpret_cast<float4*>(w.partialxA + size_t(ra3) * 4) = make_float4(qx[3], qy[3], qz[3], 0.0f);
+            }
         }
         // ---- the prefetched geometry becomes the current one
         i = i_n; jraw = j_n;
@@ -606,7 +665,8 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             d0 = ex * ex + ey * ey + ez * ez;
         }
         pqb = pq_n;
-        p2 = p2n;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) p2[g] = p2n[g];
 #pragma unroll
         for (int q = 0; q < 16; ++q) qv[q] = qn[q];
     }
@@ -616,11 +676,17 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
 __global__ void pk_xupdate_kernel(PkDims d, PkWs w, const float* __restrict__ linker_mask) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.V) return;
-    const int t0 = w.tile_off[v], nt = w.ntile[v];
+    const int q0 = w.tile_off[v], nq = w.ntile[v];
     float ax = 0.f, ay = 0.f, az = 0.f;
-    for (int k = 0; k < nt; ++k) {
-        const float4 p = *reinterpret_cast<const float4*>(w.partialx + size_t(t0 + k) * 4);
-        ax += p.x; ay += p.y; az += p.z;
+    if (nq > 0) {
+        if (q0 & 3) {
+            const float4 p = *reinterpret_cast<const float4*>(w.partialxA + size_t(v) * 4);
+            ax += p.x; ay += p.y; az += p.z;
+        }
+        for (int t = (q0 + 3) >> 2; t <= (q0 + nq - 1) >> 2; ++t) {
+            const float4 p = *reinterpret_cast<const float4*>(w.partialx + size_t(t) * 4);
+            ax += p.x; ay += p.y; az += p.z;
+        }
     }
     const float lm = linker_mask ? linker_mask[v] : 1.0f;
     const float nm = (w.flags[v] & F_REAL) ? 1.0f : 0.0f;

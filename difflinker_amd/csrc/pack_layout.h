@@ -64,6 +64,11 @@ __device__ __forceinline__ float silu_u(float y) {
     return y * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(y));
 }
 
+// the same times a power of two s, with 1/s (exact) inside the reciprocal: y * (s / (1 + 2^y)), one multiply less
+__device__ __forceinline__ float silu_scaled(float y, float inv_s) {
+    return y * __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(y), inv_s, inv_s));
+}
+
 __device__ __forceinline__ floatx16 splat16(float v) {
     floatx16 r;
 #pragma unroll
@@ -89,6 +94,13 @@ __device__ __forceinline__ float row16_allsum(float v) {
     v += dpp_mov<0x4E>(v);
     v += dpp_mov<0x141>(v);
     v += dpp_mov<0x140>(v);
+    return v;
+}
+// every lane gets the sum over its group of 8 consecutive lanes (quad_perm xor1, xor2, row_half_mirror)
+__device__ __forceinline__ float quad8_allsum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
     return v;
 }
 // every lane gets the sum over its 32-lane half (gfx950 v_permlane16_swap exchanges the two rows of a half)

@@ -69,3 +69,55 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
     bad = _lib.DLConfig(3, nf, ctx, 64, L, 2, 1, 1e-6, 100.0, 1)              # hidden_nf != 128
     assert lib.dl_model_create(ctypes.byref(bad), ptrs, len(host), ctypes.byref(model)) == -2
     assert lib.dl_error_string(-3).decode().startswith('molecule exceeds')
+
+
+def test_team_entry_points_through_raw_ctypes():
+    """ABI v5: dl_egnn_forward_fc_team / dl_team_max / dl_team_workspace_bytes without the Python drop-in: same numbers as
+    the one-workgroup entry point to fp32 rounding, documented refusals (team size, workspace size and alignment)."""
+    from difflinker_amd import _lib
+    from difflinker_amd.egnn import egnn_tensor_order
+    lib = _lib.load()
+    nf, ctx, L = 9, 1, 2
+    sd = seeded_state_dict(nf + ctx + 1, 128, L, seed=124)
+    host = [sd['dynamics.' + k].contiguous() for k in egnn_tensor_order(L)]
+    cfg = _lib.DLConfig(3, nf, ctx, 128, L, 2, 1, 1e-6, 100.0, 1)
+    ptrs = (ctypes.c_void_p * len(host))(*[t.data_ptr() for t in host])
+    model = ctypes.c_void_p()
+    assert lib.dl_model_create(ctypes.byref(cfg), ptrs, len(host), ctypes.byref(model)) == 0
+    try:
+        inp, z, t = ragged_inputs([20, 55, 9, 31, 2], [4, 7, 2, 5, 1], nf, seed=7)
+        B, N = z.shape[:2]
+        d = torch.device('cuda:0')
+        xh, tt = z.to(d).contiguous(), t.to(d).contiguous()
+        nm = inp['node_mask'].reshape(B, N).to(torch.int8).to(d).contiguous()
+        lm = inp['linker_mask'].reshape(B, N).float().to(d).contiguous()
+        em = inp['edge_mask'].reshape(B, N, N).to(torch.int8).to(d).contiguous()
+        cx = inp['context'].reshape(B, N, ctx).float().to(d).contiguous()
+        p = lambda x: ctypes.c_void_p(x.data_ptr())          # noqa: E731
+        assert lib.dl_team_max(B) == 4
+        need = lib.dl_team_workspace_bytes(B)
+        ws = torch.empty(need + 16, dtype=torch.uint8, device=d)
+        outs = {}
+        for team in (1, 2, 4):
+            out = torch.full((B, N, 3 + nf), float('nan'), device=d)
+            flags = torch.full((B,), -1, dtype=torch.int32, device=d)
+            st = lib.dl_egnn_forward_fc_team(model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags),
+                                             team, p(ws), need, None)
+            torch.cuda.synchronize()
+            assert st == 0 and flags.cpu().tolist() == [0] * B
+            outs[team] = out.cpu()
+        ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
+                                           t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        for team in (1, 2, 4):
+            assert rel_l2(outs[team][..., 3:], ref[..., 3:]) <= 2e-5
+        out = torch.empty((B, N, 3 + nf), device=d)
+        flags = torch.zeros((B,), dtype=torch.int32, device=d)
+        args = (model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags))
+        assert lib.dl_egnn_forward_fc_team(*args, 3, p(ws), need, None) == -1                 # team must be 1, 2 or 4
+        assert lib.dl_egnn_forward_fc_team(*args, 4, p(ws), need - 1, None) == -1             # workspace too small
+        assert lib.dl_egnn_forward_fc_team(*args, 4, None, need, None) == -1                  # no workspace
+        assert lib.dl_egnn_forward_fc_team(*args, 4, ctypes.c_void_p(ws.data_ptr() + 4), need, None) == -1   # not 16-byte aligned
+        assert lib.dl_egnn_forward_fc_team(*args, 1, None, 0, None) == 0                      # team 1 needs none
+        torch.cuda.synchronize()
+    finally:
+        lib.dl_model_destroy(model)

@@ -165,8 +165,13 @@ def _gloo_worker(rank, world, port, tmp):
 
     class OracleEDM:
         """Stand-in with the product EDM's sample_chain signature (the HIP EDM needs a GPU)."""
+        coef_batch = None
+        team_batch = None
+
         def sample_chain(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames=None,
                          noise_bank=None):
+            # a shard samples with the per-step scalars and the team size of the WHOLE batch (EDM.coef_batch / team_batch)
+            assert self.coef_batch == 5 and self.team_batch == 5 and x.shape[0] in (2, 3)
             o = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, ocfg), in_node_nf=nf, timesteps=500)
             o.T = T
             draws = []
@@ -175,7 +180,9 @@ def _gloo_worker(rank, world, port, tmp):
             return o.sample_chain(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
                                   edm_oracle.NoiseBank(draws), keep_frames=keep_frames)
 
-    full = sample_chain_sharded(OracleEDM(), inp, keep_frames=2, noise_bank=bank.stacked())
+    stand_in = OracleEDM()
+    full = sample_chain_sharded(stand_in, inp, keep_frames=2, noise_bank=bank.stacked())
+    assert stand_in.coef_batch is None and stand_in.team_batch is None       # pins released after the call
     lo, hi = shard_bounds(B, rank, world)
     assert (hi - lo) in (2, 3)
     if rank == 0:
