@@ -171,12 +171,14 @@ def secondary_measurements(device, a):
         t_k = (kms * 1e-3) if kms is not None else dt
         B = inp['x'].shape[0]
         out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}; {note}',
-                    'compute_units_per_molecule': None if pockets else edm.dynamics.team_for(B), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
+                    'compute_units_per_molecule': None if (pockets or config == 'C2L') else edm.dynamics.team_for(B), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
                     'roofline_frac': flops / t_k / 1e12 / peak, 'roofline_peak_tflops': peak,
                     'achieved_tflops': flops / t_k / 1e12})
 
     run('c2_fp32_mode', 'C2', None, 'fp32', 'exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), same batch as the headline')
     run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph rebuilt every forward')
+    run('c2_large_molecules', 'C2L', None, 'f16x3', '60..80 atoms per molecule: beyond the LDS-resident limit (55), HBM-resident per-pass '
+        'kernels on the dense masked edge list (dl_egnn_forward_fc_large), chain driven from the host')
     run('c2_batch_64_one_cu_each', 'C2', 64, 'f16x3', 'the reference\'s default sampling batch (generate.py:145), one compute unit per '
         'molecule: a quarter of the chip', team=1)
     for b in (64, 128, 257, 512):

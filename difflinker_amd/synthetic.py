@@ -20,6 +20,9 @@ CONFIGS = {
     'C2': dict(nf=9, ctx=1, n_layers=6, batch=256, n_max=50, n_lo=35, linker=(3, 12), T=500, graph_type='FC'),
     'C4': dict(nf=9, ctx=2, n_layers=6, batch=64, n_frag=30, n_pocket=250, linker=(6, 12), T=500,
                graph_type='FC-10A-4A'),
+    # not a BASELINE configuration: GEOM hparams on molecules beyond the LDS-resident limit of 55 atoms (bench.py's
+    # secondary line for the HBM-resident fully-connected path)
+    'C2L': dict(nf=9, ctx=1, n_layers=6, batch=64, n_max=80, n_lo=60, linker=(3, 12), T=500, graph_type='FC'),
 }
 
 
