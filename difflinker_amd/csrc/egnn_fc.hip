@@ -1752,14 +1752,14 @@ int32_t dl_team_max(int32_t B) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1;
     const int slots = (B + 7) / 8 * 8;                  // team members sit 8 workgroups apart: whole groups of 8 molecules
     int S = 1;
-    while (S < 4 && slots * (S * 2) <= cus) S *= 2;
+    while (S < TEAM_MAX && slots * (S * 2) <= cus) S *= 2;
     return S;
 }
 
 // validates a team request, zeroes the arrival words on `stream`; *grid = workgroups to launch
 static int32_t team_prepare(int32_t B, int32_t team, void* ws, size_t ws_bytes, hipStream_t stream, float** rows,
                             unsigned** flags, int* grid) {
-    if (team != 2 && team != 4) return DL_ERR_BAD_ARG;
+    if (team != 2 && team != 4 && team != 8) return DL_ERR_BAD_ARG;
     if (!ws || ws_bytes < dl_team_workspace_bytes(B) || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0) return DL_ERR_BAD_ARG;
     if (team > dl_team_max(B)) return DL_ERR_BAD_ARG;    // every workgroup of every team must be resident at once
     *rows = static_cast<float*>(ws);

@@ -203,9 +203,9 @@ class Dynamics(nn.Module):
         # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'f16x3' = scaled split-fp16 on the
         # matrix cores (default, ~3e-6 rel-L2 on a 500-step chain), 'fp32' = exact fp32 MFMA.
         self.precision = os.environ.get('DIFFLINKER_PRECISION', 'f16x3')
-        # compute units per molecule on the LDS-resident path (not a reference hyper-parameter): 'auto' = as many (1, 2
-        # or 4) as keep the whole chip busy for the batch at hand - the reference's default sampling batch of 64
-        # (generate.py:145) would otherwise light a quarter of it; 1 / 2 / 4 = fixed.  Samples agree across team sizes to
+        # compute units per molecule on the LDS-resident path (not a reference hyper-parameter): 'auto' = as many (1, 2,
+        # 4 or 8) as keep the whole chip busy for the batch at hand - the reference's default sampling batch of 64
+        # (generate.py:145) would otherwise light a quarter of it; 1 / 2 / 4 / 8 = fixed.  Samples agree across team sizes to
         # fp32 rounding (an atom's messages are summed in a team-size dependent order) and are bitwise repeatable for a
         # given one: pin it when a batch must give identical bits however it is split.
         self.team = os.environ.get('DIFFLINKER_TEAM', 'auto')
@@ -349,8 +349,8 @@ class Dynamics(nn.Module):
                 self._team_auto[key] = int(_lib.load().dl_team_max(key))
             return self._team_auto[key]
         team = int(self.team)
-        if team not in (1, 2, 4):
-            raise ValueError(f'Dynamics.team must be "auto", 1, 2 or 4, not {self.team!r}')
+        if team not in (1, 2, 4, 8):
+            raise ValueError(f'Dynamics.team must be "auto", 1, 2, 4 or 8, not {self.team!r}')
         return team
 
     def team_workspace(self, batch_size, device):

@@ -184,7 +184,7 @@ typedef struct dl_chain_args {
                                 /* both NULL: the draws are generated inside the kernel (dl_philox_fill's stream) */
     uint64_t noise_seed;        /* key of the in-kernel generator                                          */
     int32_t mol_offset;         /* global index of molecule 0 of this batch (shards of one logical batch)  */
-    int32_t team;               /* compute units per molecule: 0 or 1 = one (default); 2 or 4 = a team, see below */
+    int32_t team;               /* compute units per molecule: 0 or 1 = one (default); 2, 4 or 8 = a team, see below */
     const dl_step_coef* coefs;  /* device [T]       execution order (s = T-1 first)            */
     float inv_alpha0, sigma0, sigma_x;      /* final decode scalars (src/edm.py:213-216,237-242) */
     float norm_x, norm_h, bias_h;           /* norm_values[0], norm_values[1], norm_biases[1]    */
@@ -202,11 +202,11 @@ typedef struct dl_chain_args {
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
 
 /* Teams: a batch smaller than the chip leaves compute units idle when every molecule sits on one of them (the reference's
- * default sampling batch is 64, generate.py:145).  With team = 2 or 4 that many workgroups share a molecule: each keeps the
+ * default sampling batch is 64, generate.py:145).  With team = 2, 4 or 8 that many workgroups share a molecule: each keeps the
  * whole molecule in LDS and repeats the per-atom phases, the O(n^2) pair loop is split by receiving atom and the message
  * sums are exchanged once per pass through `team_ws` (release / acquire hand-off inside the launch, placement-independent).
  * All team * ceil(B / 8) * 8 workgroups must be resident at once: dl_team_max(B) is the largest team the current device
- * holds for a batch of B (1, 2 or 4); a larger request returns DL_ERR_BAD_ARG.  Results agree with team = 1 to fp32
+ * holds for a batch of B (1, 2, 4 or 8); a larger request returns DL_ERR_BAD_ARG.  Results agree with team = 1 to fp32
  * rounding (the order in which an atom's messages are summed depends on the team size) and are bitwise repeatable for a
  * given team size.  nan_flags bit 3: a team member did not show up within the spin limit (another kernel held its
  * compute unit for seconds); the sample is void. */

@@ -1,11 +1,17 @@
 #!/bin/bash
+# End-of-round validation on the GPU box: build check, GPU suite, smoke, the default bench line (with secondaries and CPU baseline)
 mkdir -p gpurun_out
-python -c "import __graft_entry__ as g; g.build()" > gpurun_out/build_d.log 2>&1
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/pytest_final_d.log 2>&1; tail -3 gpurun_out/pytest_final_d.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_d.log 2>&1; tail -2 gpurun_out/smoke_d.log
-timeout 600 python bench.py > gpurun_out/bench_full_d.log 2>&1; tail -1 gpurun_out/bench_full_d.log | cut -c1-400
-timeout 300 python bench.py --noise philox --no-cpu-baseline > gpurun_out/bench_full_philox_d.log 2>&1; tail -1 gpurun_out/bench_full_philox_d.log | cut -c1-300
-timeout 300 python bench.py --uniform-size --no-cpu-baseline --steps 2 > gpurun_out/bench_uniform_d.log 2>&1; tail -1 gpurun_out/bench_uniform_d.log | cut -c1-300
-timeout 600 python bench.py --config C4 --steps 2 --warmup 1 > gpurun_out/bench_c4_d.log 2>&1; tail -1 gpurun_out/bench_c4_d.log | cut -c1-300
-bash scripts/profile_gpu.sh r01d > gpurun_out/profile_r01d.log 2>&1; tail -3 gpurun_out/profile_r01d.log
-timeout 300 python scripts/phase_timeline.py --n 50 > gpurun_out/timeline_final.log 2>&1; grep -E "^forward" gpurun_out/timeline_final.log
+O=gpurun_out
+python -c "import __graft_entry__ as g; g.build()" > $O/build_final.log 2>&1; echo "build exit $?"
+timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_final.log 2>&1; echo "pytest exit $?"; tail -2 $O/pytest_final.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke_final.log 2>&1; echo "smoke exit $?"; tail -2 $O/smoke_final.log
+timeout 1500 python bench.py > $O/bench_final.log 2>&1; echo "bench exit $?"
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/bench_final.log') if x.startswith('{')][-1]
+d=json.loads(l)
+print('headline', round(d['value'],1), 'ms/step', round(d['ms_per_step'],1), 'kernel_ms', round(d['roofline']['kernel_ms'],1), 'frac', round(d['roofline']['frac'],4))
+for s in d.get('secondary',[]):
+    print(' ', s['tag'], s.get('compute_units_per_molecule'), round(s['molecules_per_s'],1), round(s['kernel_ms'] or 0,1), round(s['roofline_frac'],3))
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+PY

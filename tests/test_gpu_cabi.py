@@ -94,11 +94,11 @@ def test_team_entry_points_through_raw_ctypes():
         em = inp['edge_mask'].reshape(B, N, N).to(torch.int8).to(d).contiguous()
         cx = inp['context'].reshape(B, N, ctx).float().to(d).contiguous()
         p = lambda x: ctypes.c_void_p(x.data_ptr())          # noqa: E731
-        assert lib.dl_team_max(B) == 4
+        assert lib.dl_team_max(B) == 8
         need = lib.dl_team_workspace_bytes(B)
         ws = torch.empty(need + 16, dtype=torch.uint8, device=d)
         outs = {}
-        for team in (1, 2, 4):
+        for team in (1, 2, 4, 8):
             out = torch.full((B, N, 3 + nf), float('nan'), device=d)
             flags = torch.full((B,), -1, dtype=torch.int32, device=d)
             st = lib.dl_egnn_forward_fc_team(model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags),
@@ -108,12 +108,12 @@ def test_team_entry_points_through_raw_ctypes():
             outs[team] = out.cpu()
         ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
                                            t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
-        for team in (1, 2, 4):
+        for team in (1, 2, 4, 8):
             assert rel_l2(outs[team][..., 3:], ref[..., 3:]) <= 2e-5
         out = torch.empty((B, N, 3 + nf), device=d)
         flags = torch.zeros((B,), dtype=torch.int32, device=d)
         args = (model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags))
-        assert lib.dl_egnn_forward_fc_team(*args, 3, p(ws), need, None) == -1                 # team must be 1, 2 or 4
+        assert lib.dl_egnn_forward_fc_team(*args, 3, p(ws), need, None) == -1                 # team must be 1, 2, 4 or 8
         assert lib.dl_egnn_forward_fc_team(*args, 4, p(ws), need - 1, None) == -1             # workspace too small
         assert lib.dl_egnn_forward_fc_team(*args, 4, None, need, None) == -1                  # no workspace
         assert lib.dl_egnn_forward_fc_team(*args, 4, ctypes.c_void_p(ws.data_ptr() + 4), need, None) == -1   # not 16-byte aligned

@@ -18,7 +18,7 @@ from test_gpu_parity import (CHAIN_TOL, FWD_TOLS, check_chain, dev, make_dynamic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('team', [1, 2, 4])
+@pytest.mark.parametrize('team', [1, 2, 4, 8])
 @pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
 def test_forward_vs_oracle_per_team_size(team, precision):
     nf, L = 9, 2
@@ -44,16 +44,16 @@ def test_team_sizes_agree_to_rounding_and_full_depth():
     inp, z, t = ragged_inputs(sizes, linkers, nf, seed=78)
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     outs = {}
-    for team in (1, 2, 4):
+    for team in (1, 2, 4, 8):
         dyn.team = team
         outs[team] = run_hip_forward(dyn, inp, z, t)
         ev, eh = report(f'6 blocks, team {team}', outs[team], ref, z)
         assert ev <= FWD_TOLS['f16x3'] and eh <= FWD_TOLS['f16x3']
-    for team in (2, 4):
+    for team in (2, 4, 8):
         assert rel_l2(outs[team][..., 3:], outs[1][..., 3:]) <= 2e-6
 
 
-@pytest.mark.parametrize('team', [1, 2, 4])
+@pytest.mark.parametrize('team', [1, 2, 4, 8])
 def test_chain_vs_oracle_per_team_size(team):
     from difflinker_amd import EDM
     nf, L, T, keep = 8, 2, 12, 3
@@ -78,45 +78,49 @@ def test_chain_vs_oracle_per_team_size(team):
     assert torch.equal(got, run()), 'bitwise repeatable for a given team size'
 
 
-def test_full_length_chain_teams_against_single_workgroup():
-    """The reference's default sampling batch (64 molecules, generate.py:145) at GEOM size and depth, T = 500: 9018
-    exchanges per team.  A stale or torn exchange row anywhere would show as a gross error against team = 1."""
+@pytest.mark.parametrize('batch,teams', [(64, (4, 2)), (24, (8,))])
+def test_full_length_chain_teams_against_single_workgroup(batch, teams):
+    """The reference's default sampling batch (64 molecules, generate.py:145) - and a smaller one, for teams of 8 - at GEOM
+    size and depth, T = 500: 9018 exchanges per team.  A stale or torn exchange row anywhere would show as a gross error
+    against team = 1."""
     from difflinker_amd import EDM, synthetic
     nf, L = 9, 6
     dyn, sd, cfg = make_dynamics(nf, 1, L, seed=81, coord_gain=0.001)
-    data, _ = synthetic.make_batch('C2', seed=5, batch=64)
+    data, _ = synthetic.make_batch('C2', seed=5, batch=batch)
     inp = {k: v.to(dev()) for k, v in synthetic.sampler_inputs(data).items()}
     edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
               loss_type='l2', norm_values=[1, 4, 10]).to(dev())
     edm.noise_source = 'philox'
     chains = {}
-    for team in (1, 4, 2):
+    for team in (1,) + tuple(teams):
         dyn.team = team
         edm.noise_seed = 11
         chains[team] = edm.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
                                         inp['edge_mask'], inp['context'], keep_frames=1)[0].cpu()
         assert torch.isfinite(chains[team]).all()
     lm = inp['linker_mask'].cpu()
-    for team in (2, 4):
+    for team in teams:
         ex = rel_l2(chains[team][..., :3] * lm, chains[1][..., :3] * lm)
         mism = int((chains[team][..., 3:] != chains[1][..., 3:]).any(-1).sum())
-        print(f'[T=500, B=64, team {team} vs 1] linker-x rel-L2 {ex:.3e}, one-hot mismatches {mism}')
+        print(f'[T=500, B={batch}, team {team} vs 1] linker-x rel-L2 {ex:.3e}, one-hot mismatches {mism}')
         assert ex <= CHAIN_TOL and mism == 0
     dyn.team = 'auto'
-    assert dyn.team_for(64) == 4 and dyn.team_for(128) == 2 and dyn.team_for(129) == 1 and dyn.team_for(4096) == 1
+    assert dyn.team_for(32) == 8 and dyn.team_for(64) == 4 and dyn.team_for(128) == 2 and dyn.team_for(129) == 1 and dyn.team_for(4096) == 1
 
 
 def test_team_requests_the_device_cannot_hold_are_refused():
     from difflinker_amd import _lib
     lib = _lib.load()
-    assert lib.dl_team_max(64) == 4 and lib.dl_team_max(65) == 2 and lib.dl_team_max(128) == 2 and lib.dl_team_max(256) == 1
+    assert lib.dl_team_max(8) == 8 and lib.dl_team_max(32) == 8 and lib.dl_team_max(33) == 4 and lib.dl_team_max(64) == 4
+    assert lib.dl_team_max(65) == 2 and lib.dl_team_max(128) == 2 and lib.dl_team_max(256) == 1
     assert lib.dl_team_workspace_bytes(0) == 0 and lib.dl_team_workspace_bytes(3) == 3 * (2 * 55 * 128 * 4 + 32)
     nf = 9
     dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=5)
     inp, z, t = ragged_inputs([10] * 70, [3] * 70, nf, seed=6)          # 70 molecules: 72 slots x 4 > 256 compute units
-    dyn.team = 4
-    with pytest.raises(_lib.HipLibraryError):
-        run_hip_forward(dyn, inp, z, t)
+    for too_many in (4, 8):
+        dyn.team = too_many
+        with pytest.raises(_lib.HipLibraryError):
+            run_hip_forward(dyn, inp, z, t)
     dyn.team = 2
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     ev, eh = report('70 molecules, team 2', run_hip_forward(dyn, inp, z, t), ref, z)
