@@ -59,6 +59,7 @@ class DLChainArgs(ctypes.Structure):
         ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float),
         ('chain', ctypes.c_void_p), ('nan_flags', ctypes.c_void_p), ('nan_step', ctypes.c_void_p),
         ('order', ctypes.c_void_p), ('team_ws', ctypes.c_void_p), ('team_ws_bytes', ctypes.c_size_t),
+        ('mol_index', ctypes.c_void_p),
     ]
 
 

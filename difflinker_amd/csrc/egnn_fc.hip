@@ -1353,6 +1353,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     }
     __syncthreads();
     const bool philox = (g.noise_x == nullptr);                // draws generated in place (pack_layout.h: philox_normal)
+    const unsigned gmol = unsigned(g.mol_offset + (g.mol_index ? g.mol_index[b] : b));     // global molecule index: the noise key
     // z = normalize(x,h) * fragment_mask + noise_0 * linker_mask   (edm.py:132-137,347-350)
     for (int e = tid; e < nb * D; e += THREADS) {
         const int a = e / D, d = e - a * D;
@@ -1360,7 +1361,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         float val, eps0;
         if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = philox ? 0.0f : g.noise_x[n * 3 + d]; }
         else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = philox ? 0.0f : g.noise_h[n * nf + d - 3]; }
-        if (philox) eps0 = philox_normal(g.noise_seed, unsigned(g.mol_offset + b), unsigned(v.idx[a]), 0u, unsigned(d));
+        if (philox) eps0 = philox_normal(g.noise_seed, gmol, unsigned(v.idx[a]), 0u, unsigned(d));
         const float lm = v.lm[a];
         v.z[a * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[a]), __fmul_rn(__fmul_rn(eps0, lm), lm));
     }
@@ -1392,7 +1393,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
             const float zt = v.z[a * DMAX + d];
             const float eh = __fmul_rn(v.A[a * DMAX + d], lm);
             float nz;
-            if (philox) nz = philox_normal(g.noise_seed, unsigned(g.mol_offset + b), unsigned(v.idx[a]), unsigned(q + 1), unsigned(d));
+            if (philox) nz = philox_normal(g.noise_seed, gmol, unsigned(v.idx[a]), unsigned(q + 1), unsigned(d));
             else nz = (d < 3) ? g.noise_x[(q + 1) * nx_stride + n * 3 + d] : g.noise_h[(q + 1) * nh_stride + n * nf + d - 3];
             float zn;
             if (!decode) {

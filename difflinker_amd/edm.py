@@ -247,7 +247,13 @@ class EDM(torch.nn.Module):
             keep_frames = self.T
         else:
             assert keep_frames <= self.T
-        if not self._fused_ok() or not self.dynamics.fits_lds(node_mask):
+        bs, n = x.size(0), x.size(1)
+        big = None
+        if self._fused_ok() and n > _lib.load().dl_max_atoms():
+            big = node_mask.reshape(bs, n).ne(0).sum(1) > _lib.load().dl_max_atoms()     # molecules beyond the LDS-resident limit
+            if not bool(big.any()):
+                big = None
+        if not self._fused_ok() or (big is not None and bool(big.all())):
             philox_draws = None
             if noise_bank is None and self.noise_source == 'philox':
                 philox_draws = (int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset))   # one draw per step, no bank
@@ -257,21 +263,61 @@ class EDM(torch.nn.Module):
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.EDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
+        philox = noise_bank is None and self.noise_source == 'philox'
+        seed = 0
+        if philox:
+            seed = int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF
+            self.noise_seed = int(self.noise_seed) + 1
+        elif noise_bank is None:
+            noise_bank = self.draw_noise_bank(bs, n, dev)       # the reference's call sequence, for the whole batch
+        else:
+            noise_bank = tuple(t.to(dev, torch.float32).contiguous() for t in noise_bank)
+            assert tuple(noise_bank[0].shape) == (self.T + 2, bs, n, self.n_dims) and \
+                tuple(noise_bank[1].shape) == (self.T + 2, bs, n, self.in_node_nf)
+        if big is None:
+            return self._sample_chain_fused(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames,
+                                            noise_bank, seed, mol_offset, None)
+        # A batch with SOME molecules beyond the LDS-resident limit: those alone take the HBM-resident kernels and the
+        # host-driven loop, the rest the fused chain; noise rows and per-step scalars are those of the whole batch, so every
+        # molecule gets the sample it would get from either path alone.
+        idx_b = torch.nonzero(big).flatten()
+        idx_s = torch.nonzero(~big).flatten()
+        em = edge_mask.reshape(bs, n * n) if edge_mask is not None else None
+
+        def part(idx):
+            return dict(x=x[idx], h=h[idx], node_mask=node_mask[idx], fragment_mask=fragment_mask[idx], linker_mask=linker_mask[idx],
+                        edge_mask=em[idx].reshape(-1, 1) if em is not None else None,
+                        context=context[idx] if context is not None else None)
+        pinned = self.coef_batch
+        if pinned is None:
+            self.coef_batch = bs
+        try:
+            bank_s = bank_b = None
+            if not philox:
+                bank_s = (noise_bank[0][:, idx_s].contiguous(), noise_bank[1][:, idx_s].contiguous())
+                bank_b = (noise_bank[0][:, idx_b], noise_bank[1][:, idx_b])
+            small = self._sample_chain_fused(keep_frames=keep_frames, noise_bank=bank_s, seed=seed, mol_offset=mol_offset,
+                                             mol_index=idx_s.to(torch.int32).contiguous(), **part(idx_s))
+            large = self._sample_chain_host_loop(keep_frames=keep_frames, noise_bank=bank_b,
+                                                 philox_draws=(seed, int(mol_offset), idx_b, bs) if philox else None, **part(idx_b))
+        finally:
+            self.coef_batch = pinned
+        chain = torch.zeros((keep_frames, bs, n, self.n_dims + self.in_node_nf), device=dev)
+        chain[:, idx_s] = small
+        chain[:, idx_b] = large.to(chain.dtype)
+        return chain
+
+    def _sample_chain_fused(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames, noise_bank,
+                            seed, mol_offset, mol_index):
+        """The whole chain as ONE launch (``dl_sample_chain_fc``).  ``noise_bank`` = device tensors, or None: draws generated
+        in the kernel from ``seed`` and the molecules' global indices ``mol_offset + mol_index[b]`` (``mol_index`` None: b)."""
+        dev = x.device
         lib = _lib.load()
         bs, n = x.size(0), x.size(1)
         nf, T = self.in_node_nf, self.T
         handle = self.dynamics.hip_model(dev)
-        philox = noise_bank is None and self.noise_source == 'philox'
-        seed = 0
-        if philox:
-            noise_x = noise_h = None
-            seed = int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF
-            self.noise_seed = int(self.noise_seed) + 1
-        elif noise_bank is None:
-            noise_x, noise_h = self.draw_noise_bank(bs, n, dev)
-        else:
-            noise_x, noise_h = (t.to(dev, torch.float32).contiguous() for t in noise_bank)
-            assert tuple(noise_x.shape) == (T + 2, bs, n, self.n_dims) and tuple(noise_h.shape) == (T + 2, bs, n, nf)
+        philox = noise_bank is None
+        noise_x, noise_h = (None, None) if philox else noise_bank
         coefs, (inv_alpha0, sigma0, sigma_x) = self.step_coefficients(bs)
         coefs = coefs.to(dev)
         f32 = lambda t_, shape: t_.reshape(shape).to(torch.float32).contiguous()
@@ -299,7 +345,8 @@ class EDM(torch.nn.Module):
             inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
             norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
             chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr(), order=order.data_ptr(),
-            team_ws=team_ws.data_ptr() if team_ws is not None else None, team_ws_bytes=team_bytes)
+            team_ws=team_ws.data_ptr() if team_ws is not None else None, team_ws_bytes=team_bytes,
+            mol_index=mol_index.data_ptr() if mol_index is not None else None)
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if getattr(self, 'profile_events', False):     # bench.py: HIP events right around the launch
@@ -369,6 +416,8 @@ class EDM(torch.nn.Module):
             if noise_bank is not None:
                 return torch.cat([noise_bank[0][k].to(dev, torch.float32), noise_bank[1][k].to(dev, torch.float32)], dim=2)
             if philox_draws is not None:
+                if len(philox_draws) == 4:       # (seed, mol_offset, rows, size of the whole batch): a non-contiguous part of it
+                    return self._philox_draw(philox_draws[0], philox_draws[1], k, philox_draws[3], n_nodes, dev)[philox_draws[2]]
                 return self._philox_draw(philox_draws[0], philox_draws[1], k, n_samples, n_nodes, dev)
             return torch.cat([torch.randn((n_samples, n_nodes, self.n_dims), device=dev),
                               torch.randn((n_samples, n_nodes, self.in_node_nf), device=dev)], dim=2)

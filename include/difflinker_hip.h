@@ -197,6 +197,9 @@ typedef struct dl_chain_args {
                                  * (longest-processing-time order); results are written at the molecule's own index. */
     void* team_ws;              /* device scratch of dl_team_workspace_bytes(B) bytes, 16-byte aligned (team > 1 only) */
     size_t team_ws_bytes;
+    const int32_t* mol_index;   /* device [B] or NULL: entry b of this batch is molecule mol_offset + mol_index[b] of the
+                                 * logical batch (NULL: mol_offset + b) - the key of the in-kernel noise; lets a caller
+                                 * sample a non-contiguous part of a batch (e.g. only the molecules that fit this kernel) */
 } dl_chain_args;
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);

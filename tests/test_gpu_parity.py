@@ -265,13 +265,16 @@ def test_molecules_beyond_the_lds_limit_run_on_the_hbm_resident_kernels(sizes, l
         assert rel_l2(b.cpu(), a) <= 2e-6
 
 
-def test_chain_with_a_large_molecule_uses_the_host_loop():
-    """A batch with a > 55-atom molecule: EDM.sample_chain falls back from the fused launch to the host-driven loop of
-    HIP forwards + fused sampler tails; still the reference's numbers."""
+@pytest.mark.parametrize('sizes,linkers', [([58, 12], [6, 3]),                       # mixed: one molecule beyond the limit
+                                           ([20, 70, 35, 60, 12, 56], [4, 9, 5, 8, 3, 6]),   # mixed, interleaved
+                                           ([58, 61], [6, 7])])                     # every molecule beyond the limit
+def test_chain_with_large_molecules_splits_the_batch(sizes, linkers):
+    """Molecules with more than dl_max_atoms() atoms take the HBM-resident kernels and the host-driven loop, the rest of
+    the batch the fused launch; noise rows and per-step scalars are those of the whole batch: the reference's numbers."""
     from difflinker_amd import EDM
     nf, T, keep = 8, 6, 2
     dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=33)
-    inp, _, _ = ragged_inputs([58, 12], [6, 3], nf, seed=34)
+    inp, _, _ = ragged_inputs(sizes, linkers, nf, seed=34)
     B, N = inp['x'].shape[:2]
     edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
               loss_type='l2', norm_values=[1, 4, 10]).to(dev())
@@ -282,9 +285,27 @@ def test_chain_with_a_large_molecule_uses_the_host_loop():
     want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
                             inp['edge_mask'], inp['context'], bank, keep_frames=keep)
     g = {k: v.to(dev()) for k, v in inp.items()}
-    got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
-                           g['context'], keep_frames=keep, noise_bank=bank.stacked()).cpu()
-    check_chain('chain with a 58-atom molecule', got, want, inp)
+    args = (g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'])
+    got = edm.sample_chain(*args, keep_frames=keep, noise_bank=bank.stacked()).cpu()
+    check_chain(f'chain with molecules of {sizes} atoms', got, want, inp)
+    # the default noise: the reference's torch.randn call sequence for the WHOLE batch, whichever path a molecule takes
+    torch.manual_seed(77)
+    a = edm.sample_chain(*args, keep_frames=keep).cpu()
+    torch.manual_seed(77)
+    drawn = edm.draw_noise_bank(B, N, dev())
+    assert torch.equal(a, edm.sample_chain(*args, keep_frames=keep, noise_bank=drawn).cpu())
+    # in-kernel / per-step Philox draws keyed by the molecule's index in the whole batch
+    from oracle import philox_oracle
+    edm.noise_source, edm.noise_seed = 'philox', 5
+    got_p = edm.sample_chain(*args, keep_frames=keep).cpu()
+    assert edm.noise_seed == 6
+    rx, rh = philox_oracle.normal_bank(5, B, N, nf, T + 2)
+    draws = []
+    for k in range(T + 2):
+        draws += [rx[k], rh[k]]
+    want_p = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                              inp['edge_mask'], inp['context'], edm_oracle.NoiseBank(draws), keep_frames=keep)
+    check_chain(f'chain with molecules of {sizes} atoms, Philox noise', got_p, want_p, inp)
 
 
 def test_sampler_step_kernel_matches_oracle_arithmetic():

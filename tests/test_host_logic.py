@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.dl_abi_version() == _lib.ABI_VERSION == 5
     assert lib.dl_team_workspace_bytes(2) == 2 * (2 * 55 * 128 * 4 + 8 * 4)       # exchange rows + arrival words
-    assert ctypes.sizeof(_lib.DLChainArgs) == 184                                   # dl_chain_args of ABI v5 (LP64)
+    assert ctypes.sizeof(_lib.DLChainArgs) == 192                                   # dl_chain_args of ABI v5 (LP64)
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
     cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
