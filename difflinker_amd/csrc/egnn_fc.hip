@@ -57,7 +57,9 @@ constexpr int L_Z = L_AGGX + NMAX * 4;                // per-atom state z [n][DM
 constexpr int L_LM = L_Z + NMAX * DMAX;               // linker mask [n]
 constexpr int L_FRAG = L_LM + 56;                     // fragment mask [n]
 constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padded position [n] (int)
-constexpr int L_CTX = L_IDX + 56;                     // context [n][CTXMAX]
+constexpr int L_RCV = L_IDX + 56;                     // coordinate-pass receivers: list position -> atom [n] (int)
+constexpr int L_RPOS = L_RCV + 56;                    // atom -> position in that list, -1: not a receiver [n] (int)
+constexpr int L_CTX = L_RPOS + 56;                    // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits, [2..11] team block (TM_*)
 constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
@@ -74,10 +76,11 @@ constexpr int TM_FAIL = 3;       // a team-mate did not show up in time
 constexpr int TM_ROWS = 4;       // exchange rows of this molecule (device pointer: lo, hi)
 constexpr int TM_FLAGS = 6;      // arrival words of this molecule's workgroups (device pointer: lo, hi)
 constexpr int TM_S = 8, TM_RANK = 9, TM_R0 = 10, TM_NREC = 11;   // team size, own index, own receivers [r0, r0 + nrec)
+constexpr int MS_NRCV = 12;      // (every kernel) length of the coordinate-pass receiver list v.rcv
 
 struct Lds {
     float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag, *ctx;
-    int *idx, *misc;
+    int *idx, *rcv, *rpos, *misc;
     unsigned* fmax;
     float* dummy;
 };
@@ -88,6 +91,7 @@ __device__ __forceinline__ Lds lds_view(float* base) {
     v.xs = base + L_XS; v.x0 = base + L_X0; v.aggx = base + L_AGGX; v.z = base + L_Z;
     v.lm = base + L_LM; v.frag = base + L_FRAG; v.ctx = base + L_CTX;
     v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
+    v.rcv = reinterpret_cast<int*>(base + L_RCV); v.rpos = reinterpret_cast<int*>(base + L_RPOS);
     v.fmax = reinterpret_cast<unsigned*>(base + L_FMAX);
     v.dummy = base + L_DUMMY;
     return v;
@@ -352,14 +356,23 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                                            float norm_constant, float sa, float inv_scale, const float* __restrict__ sc,
                                            float head, Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
-    int r0 = 0, nrec = nb;                                        // receivers of this workgroup: all, or its share of a team's
-    if constexpr (TEAM) { r0 = v.misc[TM_R0]; nrec = v.misc[TM_NREC]; }
+    // receivers of this workgroup.  GCL: every atom (or its share of a team's).  Coordinate head: only the atoms whose
+    // update survives the linker mask - the reference multiplies the sum of every other atom by zero (egnn.py:113-116) -
+    // i.e. the entries of the list v.rcv (or this member's share of them)
+    int r0 = 0, nrec = EQUIV ? v.misc[MS_NRCV] : nb;
+    if constexpr (TEAM) {
+        if (EQUIV) {
+            const int S = v.misc[TM_S], rank = v.misc[TM_RANK];
+            r0 = (nrec * rank) / S;
+            nrec = (nrec * (rank + 1)) / S - r0;
+        } else { r0 = v.misc[TM_R0]; nrec = v.misc[TM_NREC]; }
+    }
     const SlotPlan pl = slot_plan(nrec, nb);
     const int q = pl.q;
     const int slot = 32 * w + c;
     const bool slot_ok = slot < nrec * pl.g;
     const int il = slot_ok ? slot / pl.g : 0;
-    const int i = r0 + il;
+    const int i = EQUIV ? (slot_ok ? v.rcv[r0 + il] : 0) : r0 + il;
     const int j0 = slot_ok ? (slot - il * pl.g) * q : 0;
     const int jn = slot_ok ? min(q, nb - j0) : 0;                 // senders this slot really has (may be <= 0)
     const bool wave_active = 32 * w < nrec * pl.g;                // wave-uniform
@@ -737,13 +750,15 @@ __device__ __forceinline__ void pair_store_gcl(const Lds& v, int nb, int tid, co
         if (e < nb * 32) *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = in.v[k];
     }
 }
-// coordinate head: aggx[i][0..2] = sum of the slot triples
+// coordinate head: aggx[i][0..2] = sum of the slot triples of receiver i (thread = atom; atoms off the list keep whatever
+// aggx holds: the update skips them)
 __device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid, float scale) {
-    const SlotPlan pl = slot_plan(nb, nb);
-    if (tid < nb) {
+    const SlotPlan pl = slot_plan(v.misc[MS_NRCV], nb);
+    const int k = tid < nb ? v.rpos[tid] : -1;
+    if (k >= 0) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int ch = 0; ch < pl.g; ++ch) {
-            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (tid * pl.g + ch));
+            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (k * pl.g + ch));
             sx += p.x; sy += p.y; sz += p.z;
         }
         v.aggx[4 * tid + 0] = sx * scale; v.aggx[4 * tid + 1] = sy * scale; v.aggx[4 * tid + 2] = sz * scale;
@@ -845,22 +860,24 @@ __device__ __forceinline__ float team_exchange_gcl(const Lds& v, int nb, int tid
 }
 // coordinate head: the triples of the own receivers -> exchange -> v.aggx of every atom
 __device__ __forceinline__ void team_exchange_equiv(const Lds& v, int nb, int tid, float scale) {
-    const int r0 = v.misc[TM_R0], nrec = v.misc[TM_NREC];
+    const int nr = v.misc[MS_NRCV], S = v.misc[TM_S], rank = v.misc[TM_RANK];
+    const int r0 = (nr * rank) / S, nrec = (nr * (rank + 1)) / S - r0;       // this member's share of the receiver list
     const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
     const SlotPlan pl = slot_plan(nrec, nb);
     const __amdgpu_buffer_rsrc_t rows = team_rows(v);
     const int pbase = int(epoch & 1u) * TEAM_ROW_BYTES;
-    if (tid < nrec) {
+    const int k = tid < nb ? v.rpos[tid] : -1;                               // thread = atom; rows are indexed by atom
+    if (k >= r0 && k < r0 + nrec) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int ch = 0; ch < pl.g; ++ch) {
-            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (tid * pl.g + ch));
+            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * ((k - r0) * pl.g + ch));
             sx += p.x; sy += p.y; sz += p.z;
         }
         const u32x4 bits = {__float_as_uint(sx * scale), __float_as_uint(sy * scale), __float_as_uint(sz * scale), 0u};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + (r0 + tid) * HID * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + tid * HID * 4, 0, 16);
     }
     team_sync(v, tid, epoch);
-    if (tid < nb) {
+    if (k >= 0) {
         const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + tid * HID * 4, 0, 16);
         v.aggx[4 * tid + 0] = __uint_as_float(bits.x); v.aggx[4 * tid + 1] = __uint_as_float(bits.y);
         v.aggx[4 * tid + 2] = __uint_as_float(bits.z);
@@ -1049,10 +1066,14 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     float n2 = 0.0f;
     if (tid < nb) {
         const float lm = v.lm[tid];
+        const bool moves = v.rpos[tid] >= 0;                     // off the receiver list: linker mask 0, nothing was summed
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float xn = v.xs[4 * tid + k] + v.aggx[4 * tid + k] * lm;
-            v.xs[4 * tid + k] = xn;
+            float xn = v.xs[4 * tid + k];
+            if (moves) {
+                xn += v.aggx[4 * tid + k] * lm;
+                v.xs[4 * tid + k] = xn;
+            }
             n2 = fmaf(xn, xn, n2);
         }
     }
@@ -1179,6 +1200,18 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
     prof_event(pf, w, lane, 4);
 }
 
+// the coordinate-pass receiver list from the linker mask in v.lm (n_b <= 55 atoms: one wave); visible after the next barrier
+__device__ __forceinline__ void build_receivers(const Lds& v, int nb, int tid) {
+    if (tid < 64) {
+        const bool rec = tid < nb && v.lm[tid] != 0.0f;
+        const unsigned long long bal = __ballot(rec);
+        const int pos = __popcll(bal & ((1ull << tid) - 1ull));
+        if (rec) v.rcv[pos] = tid;
+        if (tid < NMAX + 1) v.rpos[tid] = rec ? pos : -1;
+        if (tid == 0) v.misc[MS_NRCV] = __popcll(bal);
+    }
+}
+
 // compact the real atoms of molecule b: v.idx[0..n_b) = padded positions with node_mask != 0
 __device__ __forceinline__ int compact_atoms(const Lds& v, const int8_t* __restrict__ node_mask_b, int N, int tid) {
     if (tid < 64) {
@@ -1289,6 +1322,8 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
             v.ctx[tid * CTXMAX + k] = p.context[(size_t(b) * N + v.idx[tid]) * p.md.ctx + k];
     }
     __syncthreads();
+    build_receivers(v, nb, tid);
+    __syncthreads();
     const float tfeat = p.t[size_t(b) * p.t_stride];
     const int8_t* em = p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr;
     Prof pf;
@@ -1351,6 +1386,8 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         v.frag[tid] = g.fragment_mask[n];
         for (int k = 0; k < p.md.ctx; ++k) v.ctx[tid * CTXMAX + k] = g.context[n * p.md.ctx + k];
     }
+    __syncthreads();
+    build_receivers(v, nb, tid);
     __syncthreads();
     const bool philox = (g.noise_x == nullptr);                // draws generated in place (pack_layout.h: philox_normal)
     const unsigned gmol = unsigned(g.mol_offset + (g.mol_index ? g.mol_index[b] : b));     // global molecule index: the noise key

@@ -40,6 +40,7 @@ struct PkDims {
 struct PkWs {
     float *H, *P, *Q, *X, *X0, *partial, *partialx, *partialA, *partialxA, *pmax, *qmax, *wgt;
     int *flags, *ntile, *tile_off, *tile_row, *col, *total;   // ntile / tile_off / tile_row count QUADS (8 edge slots)
+    int* eq_tiles;                                            // tiles with a receiving atom the coordinate update keeps; count: total[1]
     size_t bytes;
 };
 
@@ -65,6 +66,7 @@ inline PkWs carve(void* base, int B, int N) {
     w.tile_off = reinterpret_cast<int*>(take((V + 1) * 4));
     w.total = reinterpret_cast<int*>(take(256));
     w.tile_row = reinterpret_cast<int*>(take(QMAX * 4));
+    w.eq_tiles = reinterpret_cast<int*>(take(TMAX * 4));
     w.col = reinterpret_cast<int*>(take(TMAX * 32 * 4));
     w.wgt = reinterpret_cast<float*>(take(TMAX * 32 * 4));     // per-edge weight (graph_type 3), 0 on padding
     // partial sums of an atom: row t of `partial` for every tile t whose FIRST quad is the atom's, row v of `partialA`
@@ -78,7 +80,7 @@ inline PkWs carve(void* base, int B, int N) {
 }
 
 // atom flags
-constexpr int F_REAL = 1, F_LIG = 2, F_POCK = 4;
+constexpr int F_REAL = 1, F_LIG = 2, F_POCK = 4, F_MOVES = 8;   // F_MOVES: linker mask != 0, the only atoms whose coordinates change
 
 // ---------------------------------------------------------------------------------------------------
 // 1. per-atom setup: masked coordinates, role flags, embedding h = We*[h_feat, t, ctx] + be
@@ -106,7 +108,8 @@ __global__ void pk_init_kernel(PkDims d, PkWs w, const float* __restrict__ wp, c
             lig = real && ((linker_mask[v] != 0.0f) || (context[size_t(v) * d.ctx + d.ctx - 2] != 0.0f));
             pock = real && (context[size_t(v) * d.ctx + d.ctx - 1] != 0.0f);
         }
-        w.flags[v] = (real ? F_REAL : 0) | (lig ? F_LIG : 0) | (pock ? F_POCK : 0);
+        const bool moves = real && (linker_mask == nullptr || linker_mask[v] != 0.0f);
+        w.flags[v] = (real ? F_REAL : 0) | (lig ? F_LIG : 0) | (pock ? F_POCK : 0) | (moves ? F_MOVES : 0);
     }
     float acc = wp[OFF_EMB_B + f];
     const float* wrow = wp + OFF_EMB_W + f * FINP;
@@ -179,7 +182,9 @@ __global__ void pk_edges_kernel(PkDims d, PkWs w) {
 }
 
 // 3. exclusive scan of ntile[0..V) -> tile_off, total quad count (single workgroup)
-__global__ void pk_scan_kernel(int V, const int* __restrict__ ntile, int* __restrict__ tile_off, int* __restrict__ total) {
+// (also marks the slots between the last quad and the end of its tile as padding: nothing else ever writes them)
+__global__ void pk_scan_kernel(int V, const int* __restrict__ ntile, int* __restrict__ tile_off, int* __restrict__ total,
+                               int* __restrict__ col, float* __restrict__ wgt) {
     __shared__ int part[1024];
     const int tid = threadIdx.x, nth = blockDim.x;
     const int per = (V + nth - 1) / nth;
@@ -196,7 +201,25 @@ __global__ void pk_scan_kernel(int V, const int* __restrict__ ntile, int* __rest
     }
     int run = part[tid] - s;
     for (int i = lo; i < hi; ++i) { tile_off[i] = run; run += ntile[i]; }
-    if (tid == nth - 1) { tile_off[V] = part[tid]; total[0] = part[tid]; }
+    if (tid == nth - 1) { tile_off[V] = part[tid]; total[0] = part[tid]; total[1] = 0; }   // total[1]: pk_eqtiles_kernel's counter
+    const int nq = part[nth - 1];                                   // every quad of every atom
+    for (int e = nq * 8 + tid; e < ((nq + 3) >> 2) * 32; e += nth) { col[e] = -1; wgt[e] = 0.0f; }
+}
+
+// 4b. the tiles of the coordinate pass: the reference multiplies the coordinate sum of every atom outside the linker mask
+//     by zero (egnn.py:113-116), so only tiles holding a quad of a linker atom are worth computing (12 % of them at the
+//     pocket configuration).  The list order is whatever the atomics give; every tile writes its own rows, so results do
+//     not depend on it.
+__global__ void pk_eqtiles_kernel(PkWs w) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nquads = w.total[0];
+    if (t >= (nquads + 3) >> 2) return;
+    bool any = false;
+    for (int g = 0; g < 4; ++g) {
+        const int qd = 4 * t + g;
+        if (qd < nquads && (w.flags[w.tile_row[qd]] & F_MOVES)) any = true;
+    }
+    if (any) w.eq_tiles[atomicAdd(&w.total[1], 1)] = t;
 }
 
 // acc[32 rows x 32 features] += A[rows][k] * W'[feature][k], k = 0..127; A = LDS tile (row stride LDT), B = pre-loaded
@@ -429,7 +452,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         const int qd = 4 * tt + qg;
         const bool in = qd < nquads;
         ii = w.tile_row[in ? qd : nquads - 1];
-        jj = in ? w.col[size_t(tt) * 32 + c] : -1;
+        jj = w.col[size_t(tt) * 32 + c];                             // (-1 past the last quad: pk_scan_kernel)
     };
 
     // Software-pipelined tile loop.  Every global access of a tile is a dependent chain (tile -> atoms -> coordinates ->
@@ -441,10 +464,14 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     //     loads per lane.
     __shared__ __attribute__((aligned(16))) float Pst[EDGE_THREADS / 64][4 * LDT];   // row stride LDT: the four rows fall into different banks
     float* pst = Pst[wv];
-    int t = gw;
+    // work list: every tile (GCL), the tiles with a linker receiver (coordinate head)
+    const int nwork = EQUIV ? w.total[1] : ntiles;
+    auto tile_of = [&](int k) { return EQUIV ? w.eq_tiles[k] : k; };
+    int idx = gw;
+    int t = idx < nwork ? tile_of(idx) : 0;
     int i = 0, jraw = -1;
     float r = 0.0f, d0 = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, pqb = 0.0f;
-    if (t < ntiles) {
+    if (idx < nwork) {
         tile_atoms(t, i, jraw);
         const int j0 = jraw >= 0 ? jraw : i;
         const float4 xi = *reinterpret_cast<const float4*>(w.X + 4 * i);
@@ -471,16 +498,16 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             qr[q] = *reinterpret_cast<const float4*>(Qrow + k);
         }
     };
-    if (t < ntiles) request_rows(i, jraw >= 0 ? jraw : i, p2, qv);
-    for (; t < ntiles; t += GW) {
+    if (idx < nwork) request_rows(i, jraw >= 0 ? jraw : i, p2, qv);
+    for (; idx < nwork; idx += GW) {
         const bool valid = jraw >= 0;
         const unsigned vmask = unsigned(__ballot(valid));           // both halves hold the same 32 slots; padding ends every atom's list
         // the quads' receiving atoms (wave-uniform)
         const int ra0 = __builtin_amdgcn_readlane(i, 0), ra1 = __builtin_amdgcn_readlane(i, 8),
                   ra2 = __builtin_amdgcn_readlane(i, 16), ra3 = __builtin_amdgcn_readlane(i, 24);
         // ---- (1) the next tile's atoms (its rows and geometry are requested mid-body, once these have arrived)
-        const int tn = t + GW;
-        const bool more = tn < ntiles;
+        const bool more = idx + GW < nwork;
+        const int tn = more ? tile_of(idx + GW) : t;
         int i_n = i, j_n = -1;
         if (more) tile_atoms(tn, i_n, j_n);
         __builtin_amdgcn_sched_barrier(0);
@@ -657,6 +684,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             }
         }
         // ---- the prefetched geometry becomes the current one
+        t = tn;
         i = i_n; jraw = j_n;
         dx = xn[0] - xn[3]; dy = xn[1] - xn[4]; dz = xn[2] - xn[5];
         {
@@ -676,6 +704,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
 __global__ void pk_xupdate_kernel(PkDims d, PkWs w, const float* __restrict__ linker_mask) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.V) return;
+    if (!(w.flags[v] & F_MOVES)) return;                           // its tiles were not even computed (pk_eqtiles_kernel)
     const int q0 = w.tile_off[v], nq = w.ntile[v];
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (nq > 0) {
@@ -758,8 +787,12 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
     hipLaunchKernelGGL(pk_init_kernel, dim3((V * HID + 255) / 256), dim3(256), 0, st, d, w, wp, xh, t,
                        t_is_scalar ? 0 : 1, node_mask, linker_mask, context);
     hipLaunchKernelGGL(pk_edges_kernel<false>, dim3((V + 3) / 4), dim3(256), 0, st, d, w);
-    hipLaunchKernelGGL(pk_scan_kernel, dim3(1), dim3(1024), 0, st, V, w.ntile, w.tile_off, w.total);
+    hipLaunchKernelGGL(pk_scan_kernel, dim3(1), dim3(1024), 0, st, V, w.ntile, w.tile_off, w.total, w.col, w.wgt);
     hipLaunchKernelGGL(pk_edges_kernel<true>, dim3((V + 3) / 4), dim3(256), 0, st, d, w);
+    {
+        const int tmax = int((size_t(V) * (N / 8 + 1) + 4) / 4 + 1);          // upper bound of the tile count (carve)
+        hipLaunchKernelGGL(pk_eqtiles_kernel, dim3((tmax + 255) / 256), dim3(256), 0, st, w);
+    }
 
     const int row_tiles = (V + 31) / 32;
     const int edge_grid = 512;                                     // 2 workgroups per CU (64 KB LDS each)
