@@ -79,7 +79,8 @@ def pocket_edge_count(inp, cutoff_cross=10.0):
     adj = (lig[:, :, None] & lig[:, None, :]) | (poc[:, :, None] & poc[:, None, :] & (d <= 4)) | \
           (((lig[:, :, None] & poc[:, None, :]) | (poc[:, :, None] & lig[:, None, :])) & (d <= cutoff_cross))
     adj = adj & nm[:, :, None] & nm[:, None, :] & ~eye
-    return int(adj.sum())
+    into_linker = adj & inp['linker_mask'].squeeze(-1).bool()[:, :, None]       # receiving atom i of edge (i, j) is a linker atom
+    return int(adj.sum()), int(into_linker.sum())
 
 
 def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
@@ -165,7 +166,7 @@ def secondary_measurements(device, a):
         dt, kms = time_chains(edm, inp)
         pairs, nodes = synthetic.pair_and_node_counts(data)
         if pockets:
-            pairs = pocket_edge_count(inp_cpu)
+            pairs, _ = pocket_edge_count(inp_cpu)
         flops = synthetic.flops_min(128, cfg['n_layers'], cfg['nf'] + cfg['ctx'] + 1, pairs, nodes) * (cfg['T'] + 1)
         peak = FP32_MFMA_PEAK_TFLOPS if precision == 'fp32' else F16_MFMA_PEAK_TFLOPS / 3.0
         t_k = (kms * 1e-3) if kms is not None else dt
@@ -229,10 +230,12 @@ def main():
     edm.profile_events = True
     shard_cpu = {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == Bg else v) for k, v in inp_cpu.items()}
     pairs, nodes = synthetic.pair_and_node_counts({'atom_mask': data['atom_mask'][lo:hi]})
+    pairs_coord = synthetic.coord_pair_count({'atom_mask': data['atom_mask'][lo:hi], 'linker_mask': data['linker_mask'][lo:hi]})
     if pockets:
-        pairs = pocket_edge_count(shard_cpu)
+        pairs, pairs_coord = pocket_edge_count(shard_cpu)
     fin = cfg['nf'] + cfg['ctx'] + 1
     flops_fwd = synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes)
+    flops_fwd_exec = synthetic.flops_executed(128, cfg['n_layers'], fin, pairs, pairs_coord, nodes)
 
     def one_chain():
         if world == 1:
@@ -266,6 +269,7 @@ def main():
 
     if rank == 0:
         achieved = flops_fwd * (cfg['T'] + 1) / (k_avg_ms * 1e-3) / 1e12
+        executed = flops_fwd_exec * (cfg['T'] + 1) / (k_avg_ms * 1e-3) / 1e12
         layer_bytes = synthetic.layer_bytes(nodes, pairs)
         t_layer = k_avg_ms * 1e-3 / ((cfg['T'] + 1) * cfg['n_layers'])
         precision = edm.dynamics.precision
@@ -300,12 +304,17 @@ def main():
                                    f'+ decode = {cfg["T"] + 1} EGNN forwards per step; random-init weights, synthetic '
                                    f'fragment graphs',
                        'global_batch': Bg, 'molecules_per_gpu': B, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}' + ('' if world == 1 else ' (distributed.sample_chain_sharded: contiguous shards, in-kernel Philox noise keyed by the global molecule index, one RCCL all-gather of the final frame)'),
-                       'real_pairs_per_forward': pairs, 'real_atoms': nodes},
+                       'real_pairs_per_forward': pairs, 'coordinate_pass_pairs_per_forward': pairs_coord, 'real_atoms': nodes},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
                          'frac_of_fp32_vector_peak': achieved / FP32_MFMA_PEAK_TFLOPS,
                          'kernel': 'sample_chain_fc_kernel' if not pockets else 'all kernels of the chain (pk_edge_kernel dominates)', 'kernel_ms': k_avg_ms,
-                         'flops_per_launch': flops_fwd * (cfg['T'] + 1)},
+                         'flops_per_launch': flops_fwd * (cfg['T'] + 1),
+                         'executed': {'achieved': executed, 'frac': executed / peak, 'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1),
+                                      'note': 'achieved / frac above count the reference algorithm (SURVEY 8d F_min: every pair in all three '
+                                              'edge models of a block); the kernels skip the coordinate head for receiving atoms outside the '
+                                              'linker mask, whose sum the reference multiplies by zero (egnn.py:113-116) - this entry counts '
+                                              'only the pairs really evaluated (' + str(pairs_coord) + ' of ' + str(pairs) + ' per coordinate pass)'}},
             'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
                           'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '

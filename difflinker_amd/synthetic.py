@@ -168,6 +168,24 @@ def flops_min(hidden_nf, n_layers, fin, pairs, nodes):
     return n_layers * (pairs * per_pair + nodes * per_node) + nodes * 4 * fin * hn
 
 
+def flops_executed(hidden_nf, n_layers, fin, pairs, pairs_coord, nodes):
+    """FLOPs the kernels really spend per ``Dynamics.forward``: ``flops_min`` with the coordinate head's edge model counted
+    only on the ``pairs_coord`` pairs whose receiving atom is inside the linker mask (the reference multiplies every other
+    atom's coordinate sum by zero, egnn.py:113-116, and the kernels do not compute what it discards)."""
+    hn = hidden_nf
+    gcl_pair = 2 * (2 * (hn * hn + 2 * hn))
+    coord_pair = 2 * ((hn * hn + 2 * hn) + hn)
+    per_node = 2 * (2 * (2 * hn * hn + hn * hn)) + 2 * 3 * (2 * hn * hn)
+    return n_layers * (pairs * gcl_pair + pairs_coord * coord_pair + nodes * per_node) + nodes * 4 * fin * hn
+
+
+def coord_pair_count(data):
+    """FC graphs: pairs (i, j) of a molecule whose receiving atom i is a linker atom = sum_b n_linker_b * n_b."""
+    n_b = data['atom_mask'].view(data['atom_mask'].shape[0], -1).sum(1).to(torch.int64)
+    n_l = data['linker_mask'].view(data['linker_mask'].shape[0], -1).sum(1).to(torch.int64)
+    return int((n_l * n_b).sum())
+
+
 def layer_bytes(nodes, pairs_fc):
     """Algorithmic HBM bytes per EquivariantBlock with h entering/leaving once (SURVEY 8d ``A_layer``)."""
     return 2 * nodes * 128 * 4 + 3 * nodes * 12 + nodes * 2 + pairs_fc
