@@ -19,6 +19,10 @@
  *   dl_sample_chain_fc                   <- EDM.sample_chain                  src/edm.py:126-176
  *                                           (+ :178-208 reverse step, :210-242 final decode,
  *                                            :328-361 noise / (un)normalisation)
+ *   dl_egnn_forward_fc_team, dl_team_max, dl_team_workspace_bytes
+ *                                        <- the same Dynamics.forward / EDM.sample_chain with several compute
+ *                                           units per molecule (batches smaller than the chip; no reference
+ *                                           counterpart: a launch-geometry knob, results agree to fp32 rounding)
  *   dl_size_model_create / dl_size_gnn_forward
  *                                        <- SizeGNN (src/linker_size.py:45-91) as driven by
  *                                           SizeClassifier.forward at inference
@@ -113,7 +117,9 @@ int32_t dl_max_atoms(void);
  *   xh          device [B,N,3+nf]   noisy state z_t (masked by node_mask inside, like the reference)
  *   t           device [B] (t_is_scalar=0) or [1] (t_is_scalar=1, the numel==1 branch :397-399)
  *   node_mask   device int8 [B,N]
- *   linker_mask device f32 [B,N] or NULL (NULL = no masking of the coordinate update, :113-114)
+ *   linker_mask device f32 [B,N] or NULL (NULL = no masking of the coordinate update, :113-114); the coordinate head
+ *               (EquivariantUpdate, :101-125) is evaluated only for receiving atoms with linker_mask != 0: the
+ *               reference multiplies every other atom's sum by zero (:113-116), so the outputs are the same
  *   edge_mask   device int8 [B,N,N] ({0,-1,-2} from collate; multiplies every message as-is) or NULL
  *               contract: edge_mask must be 0 wherever an endpoint has node_mask 0 (datasets.py:366-369)
  *   context     device f32 [B,N,ctx] or NULL when ctx == 0
