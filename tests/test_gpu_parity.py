@@ -623,3 +623,31 @@ def test_inpainting_chain_vs_reference_golden_and_oracle(golden_dir):
     chain, node_mask = m.sample_chain(data, keep_frames=1)
     assert chain.shape[1:3] == data['positions'].shape[:2] and torch.isfinite(chain).all()
     assert torch.equal(chain[0][..., 3:].sum(-1), node_mask.squeeze(-1).float())
+
+
+@pytest.mark.parametrize('team', [1, 'auto'])
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+def test_coordinate_pass_evaluates_the_linker_mask_receivers_only(team, precision):
+    """The kernels sum the coordinate head only for receiving atoms with linker_mask != 0 (the reference multiplies the
+    other sums by zero, egnn.py:113-116).  Edge cases of that list: no linker atom at all (nothing moves: velocity exactly
+    zero), every atom a linker atom, one linker atom, a fractional mask (a weight, not a switch), beside ordinary molecules."""
+    nf, L = 9, 2
+    dyn, sd, cfg = make_dynamics(nf, 1, L, seed=211, precision=precision)
+    dyn.team = team
+    sizes, linkers = [30, 22, 41, 17, 55, 9], [5, 21, 1, 3, 12, 2]
+    inp, z, t = ragged_inputs(sizes, linkers, nf, seed=212)
+    lm = inp['linker_mask'].clone()
+    lm[0] = 0.0                                            # molecule 0: no linker atom
+    lm[1, :sizes[1]] = 1.0                                 # molecule 1: every atom moves
+    lm[3, :sizes[3]] *= 0.5                                # molecule 3: its linker atoms weigh one half
+    lm[3, 0] = 0.25                                        # ... and a fragment atom moves a little too
+    inp = dict(inp, linker_mask=lm)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], lm, inp['edge_mask'], inp['context'])
+    out = run_hip_forward(dyn, inp, z, t)
+    ev, eh = report(f'receiver list edge cases, team {team} {precision}', out, ref, z)
+    assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
+    assert float(out[0, :, :3].abs().max()) == 0.0, 'no linker atom: nothing moves'
+    moved = out[..., :3].abs().sum(-1) > 0
+    assert not bool((moved & (lm.squeeze(-1) == 0)).any()), 'atoms outside the mask never move'
+    assert bool(moved[1, :sizes[1]].all()) and bool(moved[3, 0]) and int(moved[2].sum()) == 1
+    assert torch.equal(out, run_hip_forward(dyn, inp, z, t))
