@@ -276,12 +276,25 @@ class Dynamics(nn.Module):
         the kernel family); ``launch`` then only enqueues kernels."""
         dev = node_mask.device
         bs, n_nodes = node_mask.shape[0], node_mask.shape[1]
-        return dict(bs=bs, n=n_nodes, dev=dev, large=not self.fits_lds(node_mask), handle=self.hip_model(dev),
+        prep = dict(bs=bs, n=n_nodes, dev=dev, large=False, handle=self.hip_model(dev),
                     nm=node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous(),
                     lm=self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None,
                     em=edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None,
                     ctx=self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None,
                     node_mask3=node_mask.reshape(bs, n_nodes, 1))
+        limit = _lib.load().dl_max_atoms()
+        if type(self) is Dynamics and n_nodes > limit:
+            big = prep['nm'].ne(0).sum(1) > limit                  # molecules beyond the LDS-resident kernels
+            if bool(big.all()):
+                prep['large'] = True
+            elif bool(big.any()):
+                # a mixed batch: only the big molecules take the HBM-resident kernels; `launch` runs both parts and scatters
+                def part(idx, large):
+                    sub = {k: (v[idx].contiguous() if torch.is_tensor(v) else v) for k, v in prep.items()}
+                    sub.update(bs=int(idx.numel()), large=large, idx=idx)
+                    return sub
+                prep['split'] = (part(torch.nonzero(~big).flatten(), False), part(torch.nonzero(big).flatten(), True))
+        return prep
 
     def launch(self, prep, t, xh, center=True):
         """Enqueue one denoiser call for prepared masks; returns ``(eps_hat, nan_flags)`` without synchronising.
@@ -303,6 +316,16 @@ class Dynamics(nn.Module):
         lib = _lib.load()
         dev = xh.device
         bs, n_nodes = xh.shape[0], xh.shape[1]
+        if prep is not None and prep.get('split') is not None:     # molecules on both sides of the LDS-resident limit
+            out = torch.zeros_like(self._f32(xh))
+            flags = torch.zeros(bs, dtype=torch.int32, device=dev)
+            t_rows = t.to(dev).reshape(-1) if torch.is_tensor(t) and t.numel() == bs and bs > 1 else None
+            for sub in prep['split']:
+                o, f = self._launch_forward(t if t_rows is None else t_rows[sub['idx']], xh[sub['idx']], None, None, None, None,
+                                            large=sub['large'], prep=sub)
+                out[sub['idx']] = o
+                flags[sub['idx']] = f
+            return out, flags
         handle = prep['handle'] if prep is not None else self.hip_model(dev)   # a chain packs / looks up the weights once
         xh = self._f32(xh)
         if not torch.is_tensor(t):
@@ -380,8 +403,8 @@ class Dynamics(nn.Module):
         Returns eps_hat (B, N, 3 + nf) = cat[vel, h_final]; raises ``utils.FoundNaNException``.
         """
         assert self.graph_type == 'FC'
-        out, flags = self._launch_forward(t, xh, node_mask, linker_mask, edge_mask, context,
-                                          large=not self.fits_lds(node_mask))
+        prep = self.prepare(node_mask, linker_mask, edge_mask, context)
+        out, flags = self._launch_forward(t, xh, None, None, None, None, large=prep['large'], prep=prep)
         self._raise_on_flags(flags)
         if self.centering:                                     # inpainting only (egnn.py:444-445)
             nm = node_mask.reshape(xh.shape[0], xh.shape[1], 1).to(out.dtype)
