@@ -28,6 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert lib.dl_abi_version() == _lib.ABI_VERSION == 5
     assert lib.dl_team_workspace_bytes(2) == 2 * (2 * 55 * 128 * 4 + 8 * 4)       # exchange rows + arrival words
+    assert lib.dl_team_max(64) in (1, 2, 4, 8) and lib.dl_team_max(0) == 1         # 1 without a device (a query, not a compute call)
     assert ctypes.sizeof(_lib.DLChainArgs) == 192                                   # dl_chain_args of ABI v5 (LP64)
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
