@@ -9,6 +9,8 @@ struct dl_model {
     dl_config cfg;
     float* d_pack;
     size_t n_floats;
+    float* d_hsave;                 // egnn_fc.hip: per-workgroup node-feature rows across the GCL pair loops
+    size_t hsave_slots;
 };
 
 namespace {
