@@ -67,8 +67,7 @@ lib.dl_set_profile_buffer(None)
 ev = buf.cpu()
 names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: barrier', (12, 13): 'gcl: PAIR loop + partials',
          (13, 14): 'gcl: reduce + h->lds', (13, 20): 'gcl: barrier (partials complete)', (20, 21): 'gcl: sum of slot partials',
-         (21, 22): 'gcl: barrier (partials read)', (22, 23): 'gcl: W2\' DMA issue + agg store + max', (23, 24): 'gcl: h tile back from scratch',
-         (24, 25): 'gcl: h rows -> LDS', (25, 14): 'gcl: barrier (h, agg in place)', (20, 23): 'gcl: team exchange', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
+         (21, 22): 'gcl: barrier (partials read)', (22, 23): 'gcl: h rows + W2\' DMA issue, agg store, max', (23, 25): 'gcl: wait for the h rows (LDS-DMA)', (25, 14): 'gcl: barrier (h, agg in place)', (20, 23): 'gcl: team exchange', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
          (16, 10): 'gcl: end barrier', (16, 30): 'gcl: end barrier', (30, 31): 'eq: stage+proj', (31, 32): 'eq: barrier',
          (32, 33): 'eq: PAIR loop + partials', (33, 34): 'eq: reduce + x', (34, 10): 'eq: end barrier', (34, 3): 'eq: end barrier',
          (2, 10): 'h->regs', (3, 4): 'output head'}
