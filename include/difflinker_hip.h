@@ -33,6 +33,10 @@
  *   - every pointer marked "device" is a HIP device pointer owned by the caller (PyTorch-ROCm
  *     tensors' data_ptr()); the library allocates nothing per call; `stream` is a hipStream_t
  *     passed as void* (0 = default stream); calls are asynchronous on that stream.
+ *   - a dl_model owns, besides the packed weights, one scratch buffer (the node features of every workgroup across the
+ *     pair loops, 28 KB per workgroup) that grows - with a device synchronisation - the first time a launch needs more
+ *     workgroups than any before it; calls that share a dl_model must therefore be ordered (one stream), two models
+ *     are independent.
  *   - all floating point is fp32; masks are int8 (node_mask, edge_mask) or fp32 (fragment /
  *     linker masks, context) exactly as the reference's collate produces them.
  *   - return value: 0 on success, a negative dl_status otherwise; dl_error_string() names it.
