@@ -49,6 +49,20 @@ def test_no_gpu_means_loud_failure_not_fallback():
                     torch.ones(16, 1, dtype=torch.int8), torch.ones(1, 4, 1))
 
 
+def test_team_knob_of_the_dynamics():
+    """``Dynamics.team``: 'auto' asks the library (1 without a device), explicit sizes are 1, 2, 4 or 8, anything else raises."""
+    from difflinker_amd import Dynamics
+    dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+    assert dyn.team == 'auto' and dyn.team_for(64) in (1, 2, 4, 8)
+    for team in (1, 2, 4, 8, '4'):
+        dyn.team = team
+        assert dyn.team_for(8) == int(team)
+    for bad in (3, 0, 16):
+        dyn.team = bad
+        with pytest.raises(ValueError):
+            dyn.team_for(8)
+
+
 def test_unsupported_hparams_raise():
     from difflinker_amd import Dynamics
     for kw in (dict(sin_embedding=True), dict(aggregation_method='max'), dict(hidden_nf=64), dict(model='gnn_dynamics')):
