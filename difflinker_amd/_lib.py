@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('DIFFLINKER_HIP_LIB') or os.path.join(_HERE, 'libdifflinker_hip.so')
 
 DL_OK = 0
-ABI_VERSION = 5
+ABI_VERSION = 6
 PRECISIONS = {'fp32': 0, 'f16x3': 1}
 DL_ERR_TOO_MANY_ATOMS = -3
 
@@ -58,7 +58,7 @@ class DLChainArgs(ctypes.Structure):
         ('inv_alpha0', ctypes.c_float), ('sigma0', ctypes.c_float), ('sigma_x', ctypes.c_float),
         ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float),
         ('chain', ctypes.c_void_p), ('nan_flags', ctypes.c_void_p), ('nan_step', ctypes.c_void_p),
-        ('order', ctypes.c_void_p), ('team_ws', ctypes.c_void_p), ('team_ws_bytes', ctypes.c_size_t),
+        ('order', ctypes.c_void_p), ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
         ('mol_index', ctypes.c_void_p),
     ]
 
@@ -67,7 +67,7 @@ EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_stri
            'dl_model_create', 'dl_model_destroy', 'dl_egnn_forward_fc', 'dl_sampler_step', 'dl_sample_chain_fc',
            'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
            'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
-           'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large', 'dl_inpaint_step', 'dl_team_workspace_bytes',
+           'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large', 'dl_inpaint_step', 'dl_workspace_bytes',
            'dl_team_max', 'dl_egnn_forward_fc_team')
 
 _lib = None
@@ -103,11 +103,11 @@ def load():
     lib.dl_model_destroy.restype = None
     lib.dl_model_destroy.argtypes = [vp]
     lib.dl_egnn_forward_fc.restype = i32
-    lib.dl_egnn_forward_fc.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.dl_egnn_forward_fc.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
     lib.dl_egnn_forward_fc_team.restype = i32
     lib.dl_egnn_forward_fc_team.argtypes = [vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, ctypes.c_size_t, vp]
-    lib.dl_team_workspace_bytes.restype = ctypes.c_size_t
-    lib.dl_team_workspace_bytes.argtypes = [i32]
+    lib.dl_workspace_bytes.restype = ctypes.c_size_t
+    lib.dl_workspace_bytes.argtypes = [i32, i32]
     lib.dl_team_max.restype = i32
     lib.dl_team_max.argtypes = [i32]
     lib.dl_sampler_step.restype = i32

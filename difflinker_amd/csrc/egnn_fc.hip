@@ -61,13 +61,14 @@ constexpr int L_RCV = L_IDX + 56;                     // coordinate-pass receive
 constexpr int L_RPOS = L_RCV + 56;                    // atom -> position in that list, -1: not a receiver [n] (int)
 constexpr int L_CTX = L_RPOS + 56;                    // context [n][CTXMAX]
 constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits, [2..11] team block (TM_*)
-constexpr int L_FMAX = L_MISC + 16;                   // f16x3 magnitude bounds (float bits, atomicMax)
+constexpr int MISC_WORDS = 40;                        // [0..15] as listed, [16..39] the pass context (CX_*, per-atom phases v2)
+constexpr int L_FMAX = L_MISC + MISC_WORDS;           // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
 constexpr int L_TOTAL = L_DUMMY + LDH;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
-              (L_X0 % 4) == 0 && (L_AGGX % 4) == 0 && (L_Z % 4) == 0 && (L_CTX % 4) == 0, "16-byte alignment");
+              (L_X0 % 4) == 0 && (L_AGGX % 4) == 0 && (L_Z % 4) == 0 && (L_CTX % 4) == 0 && (L_DUMMY % 4) == 0, "16-byte alignment");
 
 // Team kernels (several workgroups share one molecule, see team_sync): words of v.misc.  Everything a team member needs
 // is re-read from here at the point of use, so nothing of it lives in registers across the pair loops.
@@ -139,10 +140,21 @@ __device__ __forceinline__ void loop_event(Prof& pf, int w, int lane, int tag) {
 // Unlike the f32-input MFMA - which runs at the fp32 VECTOR rate and did not overlap with this kernel's VALU
 // work - the fp16 MFMA is 16x faster, so the edge pass becomes VALU-bound (SiLU + the splits).
 // workgroup-wide max of non-negative floats into an LDS slot (slot zeroed earlier; read after a barrier)
+// (DPP / permlane steps, not __shfl_xor: the six ds_bpermute index vectors of a shuffle reduction are loop-invariant, the
+// compiler computes them once per kernel, they do not survive the pair loops in registers, and every reload from scratch
+// waits for all vector-memory traffic in flight - measured round 3: 1-2 us per maximum behind a fragment prefetch)
+__device__ __forceinline__ unsigned wave_max_u32(unsigned b) {
+    b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xf, 0xf, false));      // quad_perm xor 1
+    b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x4E, 0xf, 0xf, false));      // quad_perm xor 2
+    b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x141, 0xf, 0xf, false));     // row_half_mirror
+    b = max(b, (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x140, 0xf, 0xf, false));     // row_mirror: the 16-lane row
+    const auto r16 = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    b = max((unsigned)r16[0], (unsigned)r16[1]);                                              // both rows of the 32-lane half
+    const auto r32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return max((unsigned)r32[0], (unsigned)r32[1]);
+}
 __device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
-    unsigned b = __float_as_uint(val);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
+    const unsigned b = wave_max_u32(__float_as_uint(val));
     if (lane == 0) atomicMax(slot, b);
 }
 
@@ -715,20 +727,32 @@ struct AggRegs {
 __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out, float scale) {
     const SlotPlan pl = slot_plan(nb, nb);
     float am = 0.0f;
+    // the four groups of a thread are independent chains: their reads go out together, chunk by chunk (a group past the
+    // end of the molecule reads the last atom's rows and is discarded)
+    const float* src[4];
+    float4 s[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int e = tid + THREADS * k;
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        src[k] = v.A + min(e >> 5, nb - 1) * pl.g * PB_STRIDE + 4 * (e & 31);
+        s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int ch = 0; ch < pl.g; ++ch) {
+        float4 p[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p[k] = *reinterpret_cast<const float4*>(src[k] + ch * PB_STRIDE);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[k].x += p[k].x; s[k].y += p[k].y; s[k].z += p[k].z; s[k].w += p[k].w; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = tid + THREADS * k;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < nb * 32) {
-            const float* src = v.A + (e >> 5) * pl.g * PB_STRIDE + 4 * (e & 31);
-            for (int ch = 0; ch < pl.g; ++ch) {
-                const float4 p = *reinterpret_cast<const float4*>(src + ch * PB_STRIDE);
-                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-            }
-            s.x *= scale; s.y *= scale; s.z *= scale; s.w *= scale;      // 1, or 1/N for aggregation_method='mean'
-            am = fmaxf(fmaxf(am, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
+            r = make_float4(s[k].x * scale, s[k].y * scale, s[k].z * scale, s[k].w * scale);   // 1, or 1/N for aggregation_method='mean'
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
-        out.v[k] = s;
+        out.v[k] = r;
     }
     return am;
 }
@@ -940,12 +964,23 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
     const bool active = (mt == 0) || (nb > 32);
+#ifdef DL_V_EARLY
+    // the node MLP's first-layer fragments (32 KB per wave from L2) are requested HERE, a reduction and two barriers before
+    // their use, and AHEAD of the h rows and of the next W2' image in the memory pipeline (loads return in order)
+    BFrag b3a, b3b;
+    if (active) {
+        b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
+        b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+    }
+#endif
     lds_barrier();                         // partial rows complete
     prof_event(pf, w, lane, 20);
     if constexpr (TEAM) {
         const float am = team_exchange_gcl(v, nb, tid, md.mean ? 1.0f / float(N) : 1.0f);    // every aggregate row -> v.C
         hsave_dma(v, hs, nb, w, lane);     // h rows -> v.A
+#ifndef DL_V_EARLY
         stage_next(v, nx, w, tid);
+#endif
         if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
         if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
     } else {
@@ -955,35 +990,55 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
         lds_barrier();                     // every partial read: P, Q, H, W2' regions are free
         prof_event(pf, w, lane, 22);
         hsave_dma(v, hs, nb, w, lane);     // h rows -> v.A
+#ifndef DL_V_EARLY
         stage_next(v, nx, w, tid);         // next pass's W2' image: DMA under the node phases
+#endif
         if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
         pair_store_gcl(v, nb, tid, ar);    // aggregate -> v.C
         if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
     }
     prof_event(pf, w, lane, 23);
+#ifdef DL_V_EARLY
+    hsave_wait(false, w);
+#else
     hsave_wait(nx.base != nullptr, w);
+#endif
     prof_event(pf, w, lane, 25);
     lds_barrier();
     prof_event(pf, w, lane, 14);
     // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
     BFrag b4f;
+    floatx16 acc1;
+    float s2 = 1.0f, inv1 = 1.0f;
     if (active) {
-        // fragments requested at the point of use: issued earlier they do not fit beside the h tile, and the register
-        // allocator then waits for them just to spill them (measured: early prefetch 3.48-3.53 M ticks, this 3.38 M)
+#ifndef DL_V_EARLY
+        // fragments requested at the point of use
         BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
         BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+#endif
         const float b3 = vecs[4 * HID + 32 * nt + c];
-        float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
+        float s1 = 1.0f;
         if (PREC == 1) {
             // one accumulator for both K-blocks: common total scale S = sa_i * sw_i
             const float S = fminf(s_h * sc[2], scale_for(__uint_as_float(v.fmax[FM_AGG])) * sc[3]);
-            s1 = S * inv_pow2(sc[2]); s2 = S * inv_pow2(sc[3]); inv = inv_pow2(S);
+            s1 = S * inv_pow2(sc[2]); s2 = S * inv_pow2(sc[3]); inv1 = inv_pow2(S);
         }
-        floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
+        acc1 = splat16(PREC == 0 ? b3 : 0.0f);
         const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128<PREC>(acc, v.A, arow, hh, b3a, s1);
+        gemm_k128<PREC>(acc1, v.A, arow, hh, b3a, s1);
         b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);         // for layer 2, under layer 1's second GEMM
+#ifdef DL_V_EARLY
+    }
+    prof_event(pf, w, lane, 104);
+    stage_next(v, nx, w, tid);             // next pass's W2' image (64 KB by LDS-DMA), behind every fragment this pass still needs
+    if (active) {
+        const float b3 = vecs[4 * HID + 32 * nt + c];
+        const int arow = min(32 * mt + c, nb - 1);
+#endif
+        floatx16& acc = acc1;
+        const float inv = inv1;
         gemm_k128<PREC>(acc, v.C, arow, hh, b3b, s2);
+        prof_event(pf, w, lane, 105);
         float tmax = 0.0f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -1010,7 +1065,9 @@ __device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __re
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) acc[reg] = (PREC == 0) ? hold[reg] + b4 : 0.0f;
         const int arow = min(32 * mt + c, nb - 1);
+        prof_event(pf, w, lane, 106);
         gemm_k128<PREC>(acc, v.B, arow, hh, b4f, s_t);
+        prof_event(pf, w, lane, 107);
         float hmax = 0.0f;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -1090,6 +1147,580 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
     lds_barrier();
 }
 
+// ===================================================================================================
+// Per-atom phases, version 2 (one workgroup per molecule).  Measured on round 2's build (profiles/r03): every per-atom phase
+// of a GCL pass took 2-6 us for 0.3-1 us of matrix time - each of the four waves that share 32 atoms re-read and re-split the
+// same rows inside its GEMM (24 VALU + an exposed LDS wait per 3 MFMAs), every phase ended in a workgroup-wide maximum, and
+// the first node-MLP layer (K = 256) sat behind the pair loop.  Here:
+//   * operands of the per-atom GEMMs live in LDS as FRAGMENT ROWS: a row of 128 values = 128 fp16 "hi" parts followed by
+//     128 fp16 "lo" parts of value * s (512 bytes, the footprint of the fp32 row, same conflict-free row stride), written
+//     ONCE by the phase that produces them; a GEMM is 16 ds_read_b128 + 24 MFMAs, no VALU (fp32 mode: rows stay fp32).
+//   * the scales s are known BEFORE a phase runs: |P|, |Q|, the node MLP's hidden layer and the new h are bounded from the
+//     measured max |h| (one workgroup maximum per pass, taken where h is written) and max |agg| (taken in the reduction,
+//     whose barrier exists anyway) with the row-L1 norms of the packed matrices (host, dl_model_create).  A bound that is
+//     loose by 2^k costs nothing until k ~ 13: fp16 has 30 binades + 10 subnormal bits and the split keeps hi AND lo.
+//   * T0 = W3a' h + b3' - the half of the node MLP's first layer that does not depend on the messages - is computed BEFORE
+//     the pair loop, beside P and Q (three independent MFMA chains per wave instead of two), parked in the workgroup's HBM
+//     scratch in accumulator order and read back by the very lane that wrote it; after the loop only W3b' agg (K = 128) is left.
+//   * weight fragments, T0 and the residual rows are requested a phase ahead, always in the order they are needed
+//     (vector-memory returns in order: a prefetch issued BEFORE a load delays that load), biases ride in T0 / the residual.
+// Per-workgroup HBM scratch `hs` (floats): h rows fp32 [NMAX][HID] (residual, output head), then T0 tiles [8][16][64].
+constexpr int HS_H = 0;
+constexpr int HS_T0 = NMAX * HID;
+constexpr int HS_HT = HS_T0 + 8 * 16 * 64;    // the h rows once more, as tiles in accumulator order (the residual of the node MLP)
+constexpr int HS_STRIDE = HS_HT + 8 * 16 * 64;
+
+// Uniform scalars of the packed weights (scales, bounds) through the SCALAR cache: a vector load of them would queue behind
+// every fragment prefetch and LDS-DMA in flight (vector memory returns in order) - s_load does not.
+__device__ __forceinline__ float cload(const float* p, int k) {
+    typedef const __attribute__((address_space(4))) float* cptr_t;
+    return reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p))[k];
+}
+constexpr int FS_HS = 7;                      // v.fmax slot: scale the h fragment rows in v.C were written with (float bits)
+// host-computed bounds in the scale block of a GCL / equivariant update (pack_layout.h: G_SCALE / E_SCALE)
+constexpr int SC_L1_W1A = 12, SC_L1_W1B = 13, SC_L1_W3A = 14, SC_L1_W3B = 15, SC_L1_W4 = 16, SC_B1 = 17, SC_B3 = 18, SC_B4 = 19;
+constexpr int SCE_L1_W5A = 8, SCE_L1_W5B = 9, SCE_B5 = 10;
+
+// ---- pass context.  Whatever a pass needs besides the constant LDS addresses - sizes, pointers, which pass this is - sits in
+// v.misc[16..] and is read back (volatile, so never forwarded from an earlier read) at the point of use, before AND again
+// after the pair loop: the loop takes every VGPR and most SGPRs, a value that lives across it goes to scratch, and each
+// reload afterwards waits for ALL vector-memory traffic in flight (s_waitcnt vmcnt(0): the counter is in order) - measured
+// round 3: ten such reloads in the 2 us reduction alone.
+constexpr int CX_N = 16, CX_EM = 17, CX_HS = 19, CX_WP = 21, CX_PASS = 23, CX_PAR = 24, CX_FLAGS = 25, CX_NORMC = 26,
+              CX_CRANGE = 27, CX_INVNORM = 28, CX_NPASS = 29, CX_NF = 30, CX_FIN = 31, CX_TFEAT = 32, CX_MOL = 33;
+__device__ __forceinline__ int ctx_i(const Lds& v, int k) {
+    typedef volatile __attribute__((address_space(3))) int* lds_vint_t;       // a plain ds_read_b32 (a volatile GENERIC access is a flat sc0 sc1 load)
+    return __builtin_amdgcn_readfirstlane(*(lds_vint_t)(v.misc + k));
+}
+__device__ __forceinline__ float ctx_f(const Lds& v, int k) { return __int_as_float(ctx_i(v, k)); }
+template <class T>
+__device__ __forceinline__ T* ctx_p(const Lds& v, int k) {
+    const unsigned lo = unsigned(ctx_i(v, k)), hi = unsigned(ctx_i(v, k + 1));
+    // (through the GLOBAL address space: an integer turned into a generic pointer makes every access a flat_load / flat_store)
+    return (T*)((__attribute__((address_space(1))) T*)((unsigned long long)lo | ((unsigned long long)hi << 32)));
+}
+__device__ __forceinline__ void ctx_set_p(const Lds& v, int k, const void* ptr) {
+    const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+    v.misc[k] = int(unsigned(u)); v.misc[k + 1] = int(unsigned(u >> 32));
+}
+struct PassCtx {
+    int nb, N, pass, par, flags;
+    const float* g;             // this pass's packed weights
+    float* hs;
+    const int8_t* em;
+    NextPass nx;
+};
+__device__ __forceinline__ const float* pass_weights(const float* wp, int pass) {
+    return wp + OFF_BLOCKS + size_t(pass / 3) * BLOCK_SIZE + (pass % 3) * GCL_SIZE;     // GCL, GCL, equivariant update
+}
+__device__ __forceinline__ PassCtx pass_ctx(const Lds& v) {
+    PassCtx c;
+    c.nb = ctx_i(v, 0); c.N = ctx_i(v, CX_N); c.pass = ctx_i(v, CX_PASS); c.par = ctx_i(v, CX_PAR); c.flags = ctx_i(v, CX_FLAGS);
+    const float* wp = ctx_p<const float>(v, CX_WP);
+    c.g = pass_weights(wp, c.pass);
+    c.hs = ctx_p<float>(v, CX_HS);
+    c.em = ctx_p<const int8_t>(v, CX_EM);
+    const int nxt = c.pass + 1;
+    c.nx.base = nxt < ctx_i(v, CX_NPASS) ? pass_weights(wp, nxt) : nullptr;
+    c.nx.equiv = (nxt % 3) == 2;
+    return c;
+}
+// the kernel's own arguments through the scalar cache, re-read where used (see above)
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* kargs() {
+    auto k = (const __attribute__((address_space(4))) T*)(__builtin_amdgcn_kernarg_segment_ptr());
+    asm volatile("" : "+s"(k));
+    return k;
+}
+
+struct AReg {
+    float4 q[16];           // f16x3: q[s] / q[8+s] = hi / lo fragment of k-slab s; fp32: q[sg] = k = 64 hh + 4 sg ..
+};
+template <int PREC>
+__device__ __forceinline__ void load_a(AReg& a, const float* region, int arow, int hh) {
+    const float4* p = reinterpret_cast<const float4*>(region + arow * LDH);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if constexpr (PREC == 0) { a.q[2 * s] = p[16 * hh + 2 * s]; a.q[2 * s + 1] = p[16 * hh + 2 * s + 1]; }
+        else { a.q[s] = p[2 * s + hh]; a.q[8 + s] = p[16 + 2 * s + hh]; }
+    }
+}
+template <int PREC>
+__device__ __forceinline__ void tile_mma(floatx16& acc, const AReg& a, const BFrag& b) {
+    if constexpr (PREC == 0) {
+#pragma unroll
+        for (int sg = 0; sg < 16; ++sg) {
+            acc = mfma32(a.q[sg].x, b.q[sg].x, acc);
+            acc = mfma32(a.q[sg].y, b.q[sg].y, acc);
+            acc = mfma32(a.q[sg].z, b.q[sg].z, acc);
+            acc = mfma32(a.q[sg].w, b.q[sg].w, acc);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const uint4 ah = __builtin_bit_cast(uint4, a.q[s]), al = __builtin_bit_cast(uint4, a.q[8 + s]);
+            const uint4 bh = __builtin_bit_cast(uint4, b.q[s]), bl = __builtin_bit_cast(uint4, b.q[8 + s]);
+            acc = mfma_h(al, bh, acc);
+            acc = mfma_h(ah, bl, acc);
+            acc = mfma_h(ah, bh, acc);
+        }
+    }
+}
+// one element of a fragment row (f16x3: hi truncated, lo = the exact remainder rounded) / of an fp32 row
+template <int PREC>
+__device__ __forceinline__ void put_elem(float* rowp, int k, float val, float s) {
+    if constexpr (PREC == 0) rowp[k] = val;
+    else {
+        const float u = val * s;
+        const float uh = __uint_as_float(__float_as_uint(u) & 0xffffe000u);
+        _Float16* hp = reinterpret_cast<_Float16*>(rowp);
+        hp[k] = static_cast<_Float16>(uh);
+        hp[HID + k] = static_cast<_Float16>(u - uh);
+    }
+}
+// four consecutive elements k0 .. k0+3 (k0 % 4 == 0)
+template <int PREC>
+__device__ __forceinline__ void put_quad(float* rowp, int k0, float4 val, float s) {
+    if constexpr (PREC == 0) *reinterpret_cast<float4*>(rowp + k0) = val;
+    else {
+        const float u[4] = {val.x * s, val.y * s, val.z * s, val.w * s};
+        float h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = __uint_as_float(__float_as_uint(u[i]) & 0xffffe000u);
+        const uint2 hi = make_uint2(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1])),
+                                    __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3])));
+        const uint2 lo = make_uint2(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(u[0] - h[0], u[1] - h[1])),
+                                    __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(u[2] - h[2], u[3] - h[3])));
+        *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(rowp) + k0) = hi;
+        *reinterpret_cast<uint2*>(reinterpret_cast<_Float16*>(rowp) + HID + k0) = lo;
+    }
+}
+
+// fragments of the projections a pass opens with, requested one phase ahead: u0 = W1a' | W1b' (W5a' | W5b') by wave half,
+// u1 = W3a' (GCL only)
+struct PreW2 {
+    BFrag u0, u1;
+};
+__device__ __forceinline__ void load_pre2_u0(PreW2& pw, const NextPass& nx, int w, int lane) {
+    if (nx.base == nullptr) return;
+    const int nt = w & 3;
+    if (nx.equiv) pw.u0 = load_bfrag(nx.base + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
+    else pw.u0 = load_bfrag(nx.base + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
+}
+__device__ __forceinline__ void load_pre2_u1(PreW2& pw, const NextPass& nx, int w, int lane) {
+    if (nx.base == nullptr || nx.equiv) return;
+    pw.u1 = load_bfrag(nx.base + G_W3A + (w & 3) * (UNIT / 4), lane);
+}
+__device__ __forceinline__ void load_pre2(PreW2& pw, const NextPass& nx, int w, int lane) {
+    load_pre2_u0(pw, nx, w, lane);
+    load_pre2_u1(pw, nx, w, lane);
+}
+
+// P (waves 0-3) / Q (waves 4-7) of both atom tiles and, in a GCL, T0 of atom tile (wave half), from the h fragment rows in v.C.
+// Returns the bound on |P| + |Q| the edge pass scales its first layer with.
+template <int PREC, bool GCLP>
+__device__ __forceinline__ void pre_phase(const Lds& v, int nb, int w, int lane, const PreW2& pw, const float* __restrict__ vecs,
+                                          const float* __restrict__ sc, float* __restrict__ hs, float s_hf) {
+    const int c = lane & 31, hh = lane >> 5, nt = w & 3, half = w >> 2;
+    float* dst = half ? v.B : v.A;
+    const float bias = half ? 0.0f : vecs[32 * nt + c];                    // b1' (b5')
+    const float bias3 = GCLP ? vecs[4 * HID + 32 * nt + c] : 0.0f;         // b3'
+    float inv = 1.0f, inv3 = 1.0f;
+    if (PREC == 1) {
+        float S1 = 1.0f;                                                   // sender rows: times S1 (see geo_scale)
+        if (half) {
+            const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+            S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(sc, 6)), scale_for(4.0f * x02) * scale_for(cload(sc, 7)));
+        }
+        inv = inv_pow2(s_hf * cload(sc, half)) * S1;
+        if (GCLP) inv3 = inv_pow2(s_hf * cload(sc, 2));
+    }
+    const int mtiles = nb > 32 ? 2 : 1;
+    AReg a;
+    for (int mt = 0; mt < mtiles; ++mt) {
+        load_a<PREC>(a, v.C, min(32 * mt + c, nb - 1), hh);
+        floatx16 acc = splat16(PREC == 0 ? bias : 0.0f);
+        tile_mma<PREC>(acc, a, pw.u0);
+        const bool t0 = GCLP && half == mt;
+        floatx16 acc3;
+        if (t0) {
+            acc3 = splat16(PREC == 0 ? bias3 : 0.0f);
+            tile_mma<PREC>(acc3, a, pw.u1);
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + acc_row(reg, hh);
+            store_row(v, dst, row, nb, 32 * nt + c, (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias));
+        }
+        if (t0) {
+            float* tp = hs + HS_T0 + (4 * mt + nt) * (16 * 64) + lane;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) tp[64 * reg] = (PREC == 0) ? acc3[reg] : fmaf(acc3[reg], inv3, bias3);
+        }
+    }
+}
+
+// the projections (and T0) the NEXT pass opens with, from the h fragment rows in v.C; ends with every LDS operand of that
+// pass's pair loop in place.  Fragments are requested and used inside this one straight-line region: nothing of them is
+// carried around the pass loop (128 registers that the pair loop's 256 would push to scratch).
+template <int PREC>
+__device__ __forceinline__ void open_pass(const Lds& v, int nb, const NextPass nx, float* __restrict__ hs, Prof& pf, const PreW2& pw,
+                                          int next_pass) {
+    if (nx.base == nullptr) return;
+    const LaneIds q = lane_ids();
+    const int w = q.w, lane = q.lane;
+    const float s_hf = (PREC == 1) ? __uint_as_float(v.fmax[FS_HS]) : 1.0f;
+    if (nx.equiv) pre_phase<PREC, false>(v, nb, w, lane, pw, nx.base + E_VEC, nx.base + E_SCALE, nullptr, s_hf);
+    else pre_phase<PREC, true>(v, nb, w, lane, pw, nx.base + G_VEC, nx.base + G_SCALE, hs, s_hf);
+    if (q.tid == 0) v.misc[CX_PASS] = next_pass;
+    prof_event(pf, w, lane, 11);
+    dma_wait();
+    lds_barrier();                         // P, Q, W2', vectors in place; every read of the h rows (v.C) done
+}
+
+// GCL (egnn.py:45-80), per-atom phases version 2; P, Q, T0 of this pass are in place (open_pass).  `par`: which of the two
+// max|h| slots is current.  Ends with the next pass opened.
+template <int PREC>
+__device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
+    {   // ---- pair loop
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N, par = cx.par;
+    const int8_t* emask = cx.em;
+    const float* sc = cx.g + G_SCALE;
+    const LaneIds q = lane_ids();
+    const int tid = q.tid, w = q.w, lane = q.lane;
+    prof_event(pf, w, lane, 12);
+    if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
+    float sa = 1.0f, accs = 1.0f;
+    if (PREC == 1) {
+        const float hmax = __uint_as_float(v.fmax[FM_H0 + par]);
+        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);            // >= |P_i| + |Q_j|
+        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
+        accs = sa * cload(sc, 5);
+    }
+    if (cx.flags & 1) pair_phase<false, PREC, true, false>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, cload(sc, 8), pf);
+    else pair_phase<false, PREC, false, false>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
+    prof_event(pf, w, lane, 13);
+    }
+    // ---- aggregate, node MLP (context and lane indices re-derived: nothing lives across the loop)
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N, par = cx.par;
+    const float* g = cx.g;
+    float* hs = cx.hs;
+    const NextPass nx = cx.nx;
+    const float* vecs = g + G_VEC;
+    const float* sc = g + G_SCALE;
+    const bool mean = (cx.flags & 4) != 0;
+    const LaneIds q = lane_ids();
+    const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
+    const bool active = (mt == 0) || (nb > 32);
+    // layer 1's fragments and T0, AHEAD of the next W2' image in the memory pipeline
+    BFrag b3b, b4f;
+    float t0r[16], hold[16];
+    float b4 = 0.0f;
+    if (active) {
+        b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
+        const float* tp = hs + HS_T0 + (4 * mt + nt) * (16 * 64) + lane;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) t0r[reg] = tp[64 * reg];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();                         // partial rows complete
+    prof_event(pf, w, lane, 20);
+    AggRegs ar;
+    const float am = pair_reduce_gcl(v, nb, tid, ar, mean ? 1.0f / float(N) : 1.0f);
+    if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
+    prof_event(pf, w, lane, 21);
+    lds_barrier();                         // every partial read: P, Q, H, W2' regions are free; max |agg| known
+    prof_event(pf, w, lane, 22);
+    float hmax = 0.0f, aggmax = 0.0f, s_agg = 1.0f;
+    if (PREC == 1) {
+        hmax = __uint_as_float(v.fmax[FM_H0 + par]);
+        aggmax = __uint_as_float(v.fmax[FM_AGG]);
+        s_agg = scale_for(aggmax);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // aggregate -> fragment rows in v.C
+        const int e = tid + THREADS * k;
+        if (e < nb * 32) put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), ar.v[k], s_agg);
+    }
+    // bounds: |y3| <= L1(W3a') max|h| + L1(W3b') max|agg| + max|b3'|  >= |t| ;  |h_new| <= max|h| + L1(W4') |t| + max|b4|
+    const float y3b = cload(sc, SC_L1_W3A) * hmax + cload(sc, SC_L1_W3B) * aggmax + cload(sc, SC_B3);
+    const float s_t = (PREC == 1) ? scale_for(y3b) : 1.0f;
+    const float s_hn = (PREC == 1) ? scale_for(hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4)) : 1.0f;
+    const float inv1 = (PREC == 1) ? inv_pow2(s_agg * cload(sc, 3)) : 1.0f, inv2 = (PREC == 1) ? inv_pow2(s_t * cload(sc, 4)) : 1.0f;
+    prof_event(pf, w, lane, 23);
+    lds_barrier();
+    prof_event(pf, w, lane, 14);
+    // node MLP layer 1: t = SiLU(T0 + W3b' agg)  -> fragment rows in v.B
+    const int arow = min(32 * mt + c, nb - 1);
+    if (active) {
+        AReg a;
+        load_a<PREC>(a, v.C, arow, hh);
+        // for layer 2, under layer 1: its fragments, the residual rows (written by this lane, a pass ago), the bias
+        b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
+        const float* hp = hs + HS_HT + (4 * mt + nt) * (16 * 64) + lane;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) hold[reg] = hp[64 * reg];
+        b4 = vecs[5 * HID + 32 * nt + c];
+        __builtin_amdgcn_sched_barrier(0);
+        floatx16 acc;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[reg] = (PREC == 0) ? t0r[reg] : 0.0f;
+        tile_mma<PREC>(acc, a, b3b);
+        const float inv = inv1;
+        prof_event(pf, w, lane, 105);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + acc_row(reg, hh);
+            const float tval = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, t0r[reg]));
+            put_elem<PREC>(row < nb ? v.B + row * LDH : v.dummy, 32 * nt + c, tval, s_t);
+        }
+    }
+    prof_event(pf, w, lane, 15);
+    lds_barrier();
+    // node MLP layer 2 + residual: new h -> fragment rows in v.C, fp32 tiles in the HBM scratch
+    PreW2 pw;
+    floatx16 acc2;
+    if (active) {
+        AReg a;
+        load_a<PREC>(a, v.B, arow, hh);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc2[reg] = (PREC == 0) ? hold[reg] + b4 : 0.0f;
+        prof_event(pf, w, lane, 106);
+        tile_mma<PREC>(acc2, a, b4f);
+        prof_event(pf, w, lane, 107);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // behind layer 2's matrix instructions (their operands have been read): the fragments the next pass opens with, then the
+    // next pass's W2' image - requested in the order of use, landing under the epilogue and the barrier
+    load_pre2(pw, nx, w, lane);
+    stage_next(v, nx, w, tid);
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) {
+        floatx16& acc = acc2;
+        const float inv = inv2;
+        float hm = 0.0f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = 32 * mt + acc_row(reg, hh);
+            const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hold[reg] + b4);
+            put_elem<PREC>(row < nb ? v.C + row * LDH : v.dummy, 32 * nt + c, hv, s_hn);
+            hs[HS_HT + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hv;
+            hm = fmaxf(hm, row < nb ? fabsf(hv) : 0.0f);
+        }
+        if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
+    }
+    if (tid == 0) {
+        if (PREC == 1) v.fmax[FS_HS] = __float_as_uint(s_hn);
+        v.misc[CX_PAR] = par ^ 1;
+    }
+    prof_event(pf, w, lane, 16);
+    lds_barrier();
+    prof_event(pf, w, lane, 10);
+    open_pass<PREC>(v, nb, nx, hs, pf, pw, cx.pass + 1);
+}
+
+// EquivariantUpdate (egnn.py:101-125), per-atom phases version 2: the h fragment rows in v.C survive the pass; P, Q of
+// this pass are in place (open_pass); ends with the next pass opened.
+template <int PREC>
+__device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
+    {   // ---- pair loop
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N, par = cx.par;
+    const int8_t* emask = cx.em;
+    const float* sc = cx.g + E_SCALE;
+    const float norm_constant = ctx_f(v, CX_NORMC);
+    const LaneIds q = lane_ids();
+    const int w = q.w, lane = q.lane;
+    prof_event(pf, w, lane, 32);
+    float sa = 1.0f, accs = 1.0f;
+    if (PREC == 1) {
+        const float hmax = __uint_as_float(v.fmax[FM_H0 + par]);
+        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
+        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
+        accs = sa * cload(sc, 2);
+    }
+    pair_phase<true, PREC, false, false>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
+                                         (cx.flags & 2) ? ctx_f(v, CX_CRANGE) : 0.0f, pf);      // ends with the partial triples in LDS
+    prof_event(pf, w, lane, 33);
+    }
+    // ---- coordinate update (context and lane indices re-derived: nothing lives across the loop)
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N;
+    float* hs = cx.hs;
+    const NextPass nx = cx.nx;
+    const LaneIds q = lane_ids();
+    const int tid = q.tid, w = q.w, lane = q.lane;
+    PreW2 pw;
+    load_pre2(pw, nx, w, lane);            // the fragments the next block opens with, under the reduction
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();                         // partial triples complete
+    // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
+    const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
+    pair_reduce_equiv(v, nb, tid, xscale);
+    lds_barrier();                         // partials read: P, Q, W2' regions are free
+    stage_next(v, nx, w, tid);
+    if (PREC == 1 && tid == 0) v.fmax[FM_X2] = 0u;
+    lds_barrier();
+    float n2 = 0.0f;
+    if (tid < nb) {
+        const float lm = v.lm[tid];
+        const bool moves = v.rpos[tid] >= 0;                     // off the receiver list: linker mask 0, nothing was summed
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float xn = v.xs[4 * tid + k];
+            if (moves) {
+                xn += v.aggx[4 * tid + k] * lm;
+                v.xs[4 * tid + k] = xn;
+            }
+            n2 = fmaf(xn, xn, n2);
+        }
+    }
+    if (PREC == 1) block_max(&v.fmax[FM_X2], n2, lane);
+    prof_event(pf, w, lane, 34);
+    lds_barrier();
+    prof_event(pf, w, lane, 10);
+    open_pass<PREC>(v, nb, nx, hs, pf, pw, cx.pass + 1);
+}
+
+__device__ __forceinline__ void head_phase(const Lds& v);
+
+// Dynamics.forward for the molecule resident in LDS, per-atom phases version 2 (see forward_molecule for the contract)
+// The context words (CX_*: sizes, pointers, model flags, time feature) are set by the kernel; CX_PASS / CX_PAR are reset here.
+template <int PREC>
+__device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
+    const int tid = lane_ids().tid;
+    const int nb = ctx_i(v, 0);
+    const float* wp = ctx_p<const float>(v, CX_WP);
+    float* hs = ctx_p<float>(v, CX_HS);
+    const float tfeat = ctx_f(v, CX_TFEAT);
+    ModelDims md;
+    md.nf = ctx_i(v, CX_NF); md.fin = ctx_i(v, CX_FIN);
+    const int npass = ctx_i(v, CX_NPASS);
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
+    prof_event(pf, w, lane, 1);
+    if (PREC == 1) {
+        if (tid < 8) v.fmax[tid] = 0u;
+        __syncthreads();
+    }
+    const NextPass first = {wp + OFF_BLOCKS, false};
+    stage_next(v, first, w, tid);                                   // first pass's W2' image (v.W, v.vec are free here)
+    // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
+    if (tid < 4 * nb) {
+        const int a = tid >> 2, k = tid & 3;
+        const float xv = (k < 3) ? v.z[a * DMAX + k] : 0.0f;
+        v.xs[tid] = xv;
+        v.x0[tid] = xv;
+    }
+    if (PREC == 1) {
+        float n2 = 0.0f;
+        if (tid < nb) {
+            const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
+            n2 = x0 * x0 + x1 * x1 + x2 * x2;
+        }
+        const unsigned b = wave_max_u32(__float_as_uint(n2));
+        if (lane == 0) { atomicMax(&v.fmax[FM_X2], b); atomicMax(&v.fmax[FM_X02], b); }
+    }
+    // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224) -> fp32 rows in v.B (and the HBM scratch)
+    {
+        const int f = tid & (HID - 1);
+        float wrow[FINP];
+        const float4* wsrc = reinterpret_cast<const float4*>(wp + OFF_EMB_W + f * FINP);
+#pragma unroll
+        for (int q = 0; q < FINP / 4; ++q) {
+            const float4 t4 = wsrc[q];
+            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
+        }
+        const float be = wp[OFF_EMB_B + f];
+        float hmax = 0.0f;
+        for (int a = tid >> 7; a < nb; a += THREADS / HID) {
+            float acc = be;
+#pragma unroll
+            for (int k = 0; k < FINP; ++k) {
+                float hin = 0.0f;
+                if (k < md.nf) hin = v.z[a * DMAX + 3 + k];
+                else if (k == md.nf) hin = tfeat;
+                else if (k < md.fin) hin = v.ctx[a * CTXMAX + (k - md.nf - 1)];
+                acc = fmaf(wrow[k], hin, acc);
+            }
+            v.B[a * LDH + f] = acc;
+            {   // accumulator-order copy: row a of tile (a / 32, f / 32) sits in register (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1
+                const int r = a & 31;
+                hs[HS_HT + (((a >> 5) * 4 + (f >> 5)) * 16 + (r & 3) + 4 * (r >> 3)) * 64 + (f & 31) + 32 * ((r >> 2) & 1)] = acc;
+            }
+            hmax = fmaxf(hmax, fabsf(acc));
+        }
+        if (PREC == 1) block_max(&v.fmax[FM_H0], hmax, lane);
+    }
+    __syncthreads();
+    {   // fragment rows of the embedded h -> v.C
+        const float s0 = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
+        for (int e = tid; e < nb * 32; e += THREADS)
+            put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), *reinterpret_cast<const float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)), s0);
+        if (PREC == 1 && tid == 0) v.fmax[FS_HS] = __float_as_uint(s0);
+    }
+    __syncthreads();
+    prof_event(pf, w, lane, 2);
+    {
+        PreW2 pw;
+        load_pre2(pw, first, w, lane);
+        open_pass<PREC>(v, nb, first, hs, pf, pw, 0);
+    }
+#pragma nounroll
+    for (int p = 0; p < npass; p += 3) {
+#pragma nounroll
+        for (int gi = 0; gi < 2; ++gi) gcl_pass2<PREC>(v, pf);
+        equiv_pass2<PREC>(v, pf);
+    }
+    prof_event(pf, w, lane, 3);
+    __syncthreads();                                               // the h tiles in the HBM scratch: written by other lanes
+
+    // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
+    head_phase(v);
+    prof_event(pf, w, lane, 4);
+}
+
+// (its own context reads: the pass loop above must not keep these alive)
+__device__ __forceinline__ void head_phase(const Lds& v) {
+    const int tid = lane_ids().tid;
+    const int nb = ctx_i(v, 0), nf = ctx_i(v, CX_NF);
+    const float* wp = ctx_p<const float>(v, CX_WP);
+    const float* hs = ctx_p<const float>(v, CX_HS);
+    float* eps = v.A;
+    int nanbits = 0;
+    for (int e = tid; e < nb * nf; e += THREADS) {
+        const int a = e / nf, o = e - a * nf;
+        // row a of the accumulator-order tiles: 32 consecutive floats per feature tile (k ascending: the reference's order)
+        const int r = a & 31;
+        const float* hp = hs + HS_HT + ((a >> 5) * 4 * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1);
+        const float* wo = wp + OFF_OUT_W + o * HID;
+        float acc = wp[OFF_OUT_B + o];
+#pragma unroll
+        for (int nt4 = 0; nt4 < 4; ++nt4)
+#pragma unroll 8
+            for (int q = 0; q < 8; ++q) {
+                const float4 hv = *reinterpret_cast<const float4*>(hp + nt4 * 16 * 64 + 4 * q);
+                const float4 wv = *reinterpret_cast<const float4*>(wo + 32 * nt4 + 4 * q);
+                acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc);
+                acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+            }
+        eps[a * DMAX + 3 + o] = acc;
+        if (acc != acc) nanbits |= 2;
+    }
+    if (tid < 4 * nb && (tid & 3) < 3) {
+        const float vel = v.xs[tid] - v.x0[tid];
+        eps[(tid >> 2) * DMAX + (tid & 3)] = vel;
+        if (vel != vel) nanbits |= 1;
+    }
+    if (nanbits) atomicOr(&v.misc[1], nanbits);
+    __syncthreads();
+}
+
 // Dynamics.forward for the molecule resident in LDS: reads v.z (state), v.ctx, v.lm, time feature t;
 // writes eps_hat[a][0:3+nf] into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
 template <int PREC, bool TEAM>
@@ -1126,9 +1757,7 @@ __device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, 
             const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
             n2 = x0 * x0 + x1 * x1 + x2 * x2;
         }
-        unsigned b = __float_as_uint(n2);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
+        const unsigned b = wave_max_u32(__float_as_uint(n2));
         if (lane == 0) { atomicMax(&v.fmax[FM_X2], b); atomicMax(&v.fmax[FM_X02], b); }
     }
     // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224)
@@ -1334,7 +1963,7 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     Prof pf;
     pf.buf = (b == 0 && rank == 0) ? p.prof : nullptr;
     pf.n = 0;
-    forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf, p.hsave + size_t(blockIdx.x) * (NMAX * HID));
+    forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf, p.hsave + size_t(blockIdx.x) * HS_STRIDE);
     if (!writer) return;
     for (int e = tid; e < nb * D; e += THREADS) {
         const int a = e / D, d = e - a * D;
@@ -1420,7 +2049,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         Prof pf;
         pf.buf = (blockIdx.x == 0 && q == 0) ? p.prof : nullptr;
         pf.n = 0;
-        forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf, p.hsave + size_t(blockIdx.x) * (NMAX * HID));
+        forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf, p.hsave + size_t(blockIdx.x) * HS_STRIDE);
         if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
             if (writer && tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
             return;
@@ -1470,6 +2099,220 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
             if (hv > bv) { bv = hv; best = k; }
         }
         for (int k = 0; k < nf; ++k) o[3 + k] = (k == best) ? 1.0f : 0.0f;   // one_hot * node_mask (=1 here)
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Kernels 1b / 2b: the same two entry points for ONE workgroup per molecule (batches that fill the chip - the benchmarked
+// configuration), on the per-atom phases version 2.  Everything a phase needs is re-read from the LDS context block or from the
+// kernel arguments (scalar cache) where it is used; the team kernels above keep round 2's code until they move over too.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ctx_store(const Lds& v, const ModelDims& md, int N, const int8_t* em, float* hs, const float* wp,
+                                          float tfeat, int mol) {
+    v.misc[CX_N] = N;
+    ctx_set_p(v, CX_EM, em); ctx_set_p(v, CX_HS, hs); ctx_set_p(v, CX_WP, wp);
+    v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0;
+    v.misc[CX_FLAGS] = (md.attention ? 1 : 0) | (md.tanh ? 2 : 0) | (md.mean ? 4 : 0);
+    v.misc[CX_NORMC] = __float_as_int(md.norm_constant); v.misc[CX_CRANGE] = __float_as_int(md.coords_range);
+    v.misc[CX_INVNORM] = __float_as_int(md.inv_norm);
+    v.misc[CX_NPASS] = 3 * md.n_layers; v.misc[CX_NF] = md.nf; v.misc[CX_FIN] = md.fin;
+    v.misc[CX_TFEAT] = __float_as_int(tfeat); v.misc[CX_MOL] = mol;
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel2(FwdArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
+    const Lds v = lds_view(lds_raw);
+    {
+        const int tid = threadIdx.x;
+        const int b = blockIdx.x;
+        const int N = p.N, D = 3 + p.md.nf;
+        const int8_t* nm = p.node_mask + size_t(b) * N;
+        float* out_b = p.out + size_t(b) * N * D;
+        const int nb = compact_atoms(v, nm, N, tid);
+        // padded rows of the output are exactly zero (node_mask multiply, egnn.py:420,236-237)
+        for (int e = tid; e < N * D; e += THREADS)
+            if (nm[e / D] == 0 || nb > NMAX) out_b[e] = 0.0f;
+        if (nb > NMAX || nb == 0) {
+            if (tid == 0) p.nan_flags[b] = (nb > NMAX) ? 4 : 0;
+            return;
+        }
+        const float* xh_b = p.xh + size_t(b) * N * D;
+        for (int e = tid; e < nb * D; e += THREADS) {
+            const int a = e / D, d = e - a * D;
+            v.z[a * DMAX + d] = xh_b[v.idx[a] * D + d];
+        }
+        if (tid < nb) {
+            v.lm[tid] = p.linker_mask ? p.linker_mask[size_t(b) * N + v.idx[tid]] : 1.0f;
+            for (int k = 0; k < p.md.ctx; ++k)
+                v.ctx[tid * CTXMAX + k] = p.context[(size_t(b) * N + v.idx[tid]) * p.md.ctx + k];
+        }
+        if (tid == 0)
+            ctx_store(v, p.md, N, p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr, p.hsave + size_t(b) * HS_STRIDE, p.wpack,
+                      p.t[size_t(b) * p.t_stride], b);
+        __syncthreads();
+        build_receivers(v, nb, tid);
+        __syncthreads();
+    }
+    Prof pf;
+    pf.buf = (blockIdx.x == 0) ? p.prof : nullptr;
+    pf.n = 0;
+    forward_molecule2<PREC>(v, pf);
+    {   // results (arguments and sizes re-read: see the pass context)
+        const auto* P = kargs<FwdArgs>();
+        const int tid = lane_ids().tid;
+        const int b = blockIdx.x, nb = ctx_i(v, 0), N = P->N, D = 3 + P->md.nf;
+        float* out_b = P->out + size_t(b) * N * D;
+        for (int e = tid; e < nb * D; e += THREADS) {
+            const int a = e / D, d = e - a * D;
+            out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
+        }
+        if (tid == 0) P->nan_flags[b] = v.misc[1];
+    }
+}
+
+// one reverse step (or the final decode, q == T) of the molecule in LDS: denoiser, then the sampler algebra.  false: NaN, stop.
+template <int PREC>
+__device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
+    {
+        const auto* P = kargs<ChainArgs>();
+        const int tid = lane_ids().tid;
+        if (tid == 0) {
+            const float t = (q == P->a.T) ? 0.0f : P->a.coefs[q].t;                  // last forward: p(x,h | z_0), edm.py:210-242
+            v.misc[CX_TFEAT] = __float_as_int(t);
+        }
+        __syncthreads();
+    }
+    Prof pf;
+    pf.buf = (blockIdx.x == 0 && q == 0) ? kargs<ChainArgs>()->prof : nullptr;
+    pf.n = 0;
+    forward_molecule2<PREC>(v, pf);
+    const auto* P = kargs<ChainArgs>();
+    const int tid = lane_ids().tid;
+    const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0);
+    const int N = P->a.N, nf = P->md.nf, D = 3 + nf, T = P->a.T, K = P->a.keep_frames, B = P->a.B;
+    if (v.misc[1] != 0) {                                      // FoundNaNException (egnn.py:441-442)
+        if (tid == 0) { P->a.nan_flags[b] = v.misc[1]; P->a.nan_step[b] = q; }
+        return false;
+    }
+    const bool decode = (q == T);
+    dl_step_coef cf;
+    if (decode) { cf.t = 0.0f; cf.alpha_ts = 1.0f; cf.c_eps = 0.0f; cf.sigma = 0.0f; }
+    else cf = P->a.coefs[q];
+    const float* noise_x = P->a.noise_x;
+    const float* noise_h = P->a.noise_h;
+    const bool philox = (noise_x == nullptr);
+    const unsigned gmol = unsigned(P->a.mol_offset + (P->a.mol_index ? P->a.mol_index[b] : b));
+    const unsigned long long seed = P->a.noise_seed;
+    const size_t frame = size_t(B) * N * D;
+    const size_t nx_stride = size_t(B) * N * 3, nh_stride = size_t(B) * N * nf;
+    float* chain_b = P->a.chain + size_t(b) * N * D;
+    const float norm_x = P->a.norm_x, norm_h = P->a.norm_h, bias_h = P->a.bias_h;
+    const float inv_alpha0 = P->a.inv_alpha0, sigma0 = P->a.sigma0, sigma_x = P->a.sigma_x;
+    const int s = T - 1 - q;
+    const int widx = decode ? 0 : (s * K) / T;
+    const bool last_writer = (s == 0) || (((s - 1) * K) / T != widx);
+    const bool write = !decode && last_writer && widx != 0;   // frame 0 is overwritten by the decode
+    for (int e = tid; e < nb * D; e += THREADS) {
+        const int a = e / D, d = e - a * D;
+        const size_t n = size_t(b) * N + v.idx[a];
+        const float lm = v.lm[a];
+        const float zt = v.z[a * DMAX + d];
+        const float eh = __fmul_rn(v.A[a * DMAX + d], lm);
+        float nz;
+        if (philox) nz = philox_normal(seed, gmol, unsigned(v.idx[a]), unsigned(q + 1), unsigned(d));
+        else nz = (d < 3) ? noise_x[(q + 1) * nx_stride + n * 3 + d] : noise_h[(q + 1) * nh_stride + n * nf + d - 3];
+        float zn;
+        if (!decode) {
+            // z_s = z_t*frag + (z_t/alpha - c_eps*(eps*lm) + sigma*(noise*lm))*lm   (edm.py:196-206)
+            const float mu = __fsub_rn(__fdiv_rn(zt, cf.alpha_ts), __fmul_rn(cf.c_eps, eh));
+            const float zs = __fadd_rn(mu, __fmul_rn(cf.sigma, __fmul_rn(nz, lm)));
+            zn = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(zs, lm));
+            if (write) {                                   // chain[widx] = unnormalize_z(z) (edm.py:162-163)
+                const float o = (d < 3) ? __fmul_rn(zn, norm_x) : __fadd_rn(__fmul_rn(zn, norm_h), bias_h);
+                chain_b[widx * frame + v.idx[a] * D + d] = o;
+            }
+        } else {
+            // xh = z_0*frag + (1/alpha_0*(z_0 - sigma_0*eps) + sigma_x*(noise*lm))*lm, then unnormalize
+            const float mu = __fmul_rn(inv_alpha0, __fsub_rn(zt, __fmul_rn(sigma0, eh)));
+            const float xh = __fadd_rn(mu, __fmul_rn(sigma_x, __fmul_rn(nz, lm)));
+            const float zz = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(xh, lm));
+            zn = (d < 3) ? __fmul_rn(zz, norm_x) : __fadd_rn(__fmul_rn(zz, norm_h), bias_h);
+        }
+        v.z[a * DMAX + d] = zn;
+    }
+    __syncthreads();
+    return true;
+}
+
+template <int PREC>
+__global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel2(ChainArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
+    const Lds v = lds_view(lds_raw);
+    int T;
+    {
+        const dl_chain_args& g = p.a;
+        const int tid = threadIdx.x;
+        const int k = blockIdx.x;
+        const int b = g.order ? g.order[k] : k;
+        const int N = g.N, nf = p.md.nf, D = 3 + nf, K = g.keep_frames, B = g.B;
+        T = g.T;
+        const int8_t* nm = g.node_mask + size_t(b) * N;
+        const size_t frame = size_t(B) * N * D;
+        float* chain_b = g.chain + size_t(b) * N * D;
+        const int nb = compact_atoms(v, nm, N, tid);
+        if (tid == 0) { g.nan_flags[b] = (nb > NMAX) ? 4 : 0; g.nan_step[b] = -1; }
+        // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
+        for (int kf = 0; kf < K; ++kf)
+            for (int e = tid; e < N * D; e += THREADS)
+                if (nm[e / D] == 0 || nb > NMAX) chain_b[kf * frame + e] = 0.0f;
+        if (nb > NMAX || nb == 0) return;
+        if (tid < nb) {
+            const size_t n = size_t(b) * N + v.idx[tid];
+            v.lm[tid] = g.linker_mask[n];
+            v.frag[tid] = g.fragment_mask[n];
+            for (int kk = 0; kk < p.md.ctx; ++kk) v.ctx[tid * CTXMAX + kk] = g.context[n * p.md.ctx + kk];
+        }
+        if (tid == 0)
+            ctx_store(v, p.md, N, g.edge_mask ? g.edge_mask + size_t(b) * N * N : nullptr, p.hsave + size_t(k) * HS_STRIDE, p.wpack,
+                      0.0f, b);
+        __syncthreads();
+        build_receivers(v, nb, tid);
+        __syncthreads();
+        const bool philox = (g.noise_x == nullptr);                // draws generated in place (pack_layout.h: philox_normal)
+        const unsigned gmol = unsigned(g.mol_offset + (g.mol_index ? g.mol_index[b] : b));     // global molecule index: the noise key
+        // z = normalize(x,h) * fragment_mask + noise_0 * linker_mask   (edm.py:132-137,347-350)
+        for (int e = tid; e < nb * D; e += THREADS) {
+            const int a = e / D, d = e - a * D;
+            const size_t n = size_t(b) * N + v.idx[a];
+            float val, eps0;
+            if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = philox ? 0.0f : g.noise_x[n * 3 + d]; }
+            else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = philox ? 0.0f : g.noise_h[n * nf + d - 3]; }
+            if (philox) eps0 = philox_normal(g.noise_seed, gmol, unsigned(v.idx[a]), 0u, unsigned(d));
+            const float lm = v.lm[a];
+            v.z[a * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[a]), __fmul_rn(__fmul_rn(eps0, lm), lm));
+        }
+        __syncthreads();
+    }
+#pragma nounroll
+    for (int q = 0; q <= T; ++q)
+        if (!chain_step2<PREC>(v, q)) return;
+    {   // frame 0: the final sample [x, one_hot(h)]
+        const auto* P = kargs<ChainArgs>();
+        const int tid = lane_ids().tid;
+        const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), nf = P->md.nf, D = 3 + nf;
+        if (tid < nb) {
+            const int a = tid;
+            float* o = P->a.chain + size_t(b) * P->a.N * D + v.idx[a] * D;
+            o[0] = v.z[a * DMAX + 0]; o[1] = v.z[a * DMAX + 1]; o[2] = v.z[a * DMAX + 2];
+            int best = 0;                                          // torch.argmax: first maximal index
+            float bv = v.z[a * DMAX + 3];
+            for (int kk = 1; kk < nf; ++kk) {
+                const float hv = v.z[a * DMAX + 3 + kk];
+                if (hv > bv) { bv = hv; best = kk; }
+            }
+            for (int kk = 0; kk < nf; ++kk) o[3 + kk] = (kk == best) ? 1.0f : 0.0f;   // one_hot * node_mask (=1 here)
+        }
     }
 }
 
@@ -1612,6 +2455,17 @@ double pack_lds_image_f16_t(float* dstf, const float* w, int ld, double scale) {
     return sw;
 }
 
+// largest row L1 norm of scale * W[:, col0 : col0 + 128] (a bound: rounded up)
+float row_l1(const float* w, int ld, int col0, double scale) {
+    double m = 0.0;
+    for (int f = 0; f < HID; ++f) {
+        double r = 0.0;
+        for (int k = 0; k < HID; ++k) r += fabs(double(w[size_t(f) * ld + col0 + k]) * scale);
+        m = fmax(m, r);
+    }
+    return float(m * 1.0001);
+}
+
 float vec_absmax(const float* v) {
     float m = 0.0f;
     for (int f = 0; f < HID; ++f) m = fmaxf(m, fabsf(v[f]));
@@ -1739,6 +2593,12 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             if (watt) { pack_vec(vv + 6 * HID, watt, 1, 1.0 / c); sc[8] = batt[0]; }    // logit = w_att . (u2 / c) + b_att
             sc[6] = vec_absmax(vv + 1 * HID);
             sc[7] = vec_absmax(vv + 2 * HID);
+            // bounds for the a-priori scales of the per-atom phases (version 2): row L1 norms of the packed matrices, bias maxima
+            sc[12] = row_l1(w1, ld1, 0, c); sc[13] = row_l1(w1, ld1, HID, c);
+            sc[14] = row_l1(w3, 2 * HID, 0, c); sc[15] = row_l1(w3, 2 * HID, HID, cfg->aggregation_mean ? 1.0 : inv_norm);
+            sc[16] = row_l1(w4, HID, 0, 1.0 / c);
+            sc[17] = vec_absmax(vv + 0 * HID) * 1.0001f; sc[18] = vec_absmax(vv + 4 * HID) * 1.0001f;
+            sc[19] = vec_absmax(vv + 5 * HID) * 1.0001f;
         }
         float* e = base + 2 * GCL_SIZE;
         const float* w5 = w[ti++]; const float* b5 = w[ti++];         // coord_mlp.0 [128][258]
@@ -1759,6 +2619,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         pack_vec(vv + 4 * HID, w7, 1, (cfg->tanh || cfg->aggregation_mean) ? 1.0 / c : inv_norm / c);
         sc[6] = vec_absmax(vv + 1 * HID);
         sc[7] = vec_absmax(vv + 2 * HID);
+        sc[8] = row_l1(w5, ld5, 0, c); sc[9] = row_l1(w5, ld5, HID, c); sc[10] = vec_absmax(vv + 0 * HID) * 1.0001f;
     }
     dl_model* m = static_cast<dl_model*>(calloc(1, sizeof(dl_model)));
     if (!m) { free(hp); return DL_ERR_ALLOC; }
@@ -1778,31 +2639,20 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
 void dl_model_destroy(dl_model* m) {
     if (!m) return;
     if (m->d_pack) (void)hipFree(m->d_pack);
-    if (m->d_hsave) (void)hipFree(m->d_hsave);
     free(m);
 }
 
-// The per-workgroup h rows (hsave_dma) live in a buffer the model handle owns: grown when a launch needs more workgroups
-// than any before it (hipFree / hipMalloc synchronise the device: once per model and batch size, not per call).  Launches
-// that share a model handle are expected on one stream, like the rest of the handle's state.
-static float* ensure_hsave(const dl_model* m, int grid) {
-    dl_model* mm = const_cast<dl_model*>(m);
-    if (mm->hsave_slots < size_t(grid)) {
-        if (mm->d_hsave) (void)hipFree(mm->d_hsave);
-        mm->d_hsave = nullptr; mm->hsave_slots = 0;
-        const size_t slots = size_t(std::max(grid, 256));
-        if (!hip_ok(hipMalloc(reinterpret_cast<void**>(&mm->d_hsave), slots * NMAX * HID * sizeof(float)))) return nullptr;
-        mm->hsave_slots = slots;
-    }
-    return mm->d_hsave;
-}
-
-// ---- teams (several compute units per molecule): workspace layout and launch geometry
+// ---- workspace (caller-owned, sized by dl_workspace_bytes): [h rows of every workgroup][team exchange rows][arrival words]
+// and launch geometry.  The library allocates nothing after dl_model_create.
+static int fc_grid(int32_t B, int32_t team) { return team <= 1 ? B : (B + 7) / 8 * 8 * team; }
+static size_t hsave_bytes(int32_t B, int32_t team) { return size_t(fc_grid(B, team)) * HS_STRIDE * sizeof(float); }
 static size_t team_rows_bytes(int32_t B) { return size_t(B) * 2 * TEAM_ROW_BYTES; }
 
-size_t dl_team_workspace_bytes(int32_t B) {
-    if (B <= 0) return 0;
-    return team_rows_bytes(B) + size_t(B) * TEAM_MAX * sizeof(unsigned);
+size_t dl_workspace_bytes(int32_t B, int32_t team) {
+    if (B <= 0 || team < 0 || team > TEAM_MAX) return 0;
+    size_t n = hsave_bytes(B, team);
+    if (team > 1) n += team_rows_bytes(B) + size_t(B) * TEAM_MAX * sizeof(unsigned);
+    return n;
 }
 
 int32_t dl_team_max(int32_t B) {
@@ -1816,23 +2666,34 @@ int32_t dl_team_max(int32_t B) {
     return S;
 }
 
-// validates a team request, zeroes the arrival words on `stream`; *grid = workgroups to launch
-static int32_t team_prepare(int32_t B, int32_t team, void* ws, size_t ws_bytes, hipStream_t stream, float** rows,
-                            unsigned** flags, int* grid) {
-    if (team != 2 && team != 4 && team != 8) return DL_ERR_BAD_ARG;
-    if (!ws || ws_bytes < dl_team_workspace_bytes(B) || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0) return DL_ERR_BAD_ARG;
-    if (team > dl_team_max(B)) return DL_ERR_BAD_ARG;    // every workgroup of every team must be resident at once
-    *rows = static_cast<float*>(ws);
-    *flags = reinterpret_cast<unsigned*>(static_cast<char*>(ws) + team_rows_bytes(B));
-    *grid = (B + 7) / 8 * 8 * team;
-    if (!hip_ok(hipMemsetAsync(*flags, 0, size_t(B) * TEAM_MAX * sizeof(unsigned), stream))) return DL_ERR_HIP;
+// splits the caller's workspace; for a team request validates it and zeroes the arrival words on `stream`
+struct FcWorkspace {
+    float* hsave;
+    float* rows;
+    unsigned* flags;
+    int grid;
+};
+static int32_t fc_workspace(int32_t B, int32_t team, void* ws, size_t ws_bytes, hipStream_t stream, FcWorkspace* out) {
+    if (team > 1 && team != 2 && team != 4 && team != 8) return DL_ERR_BAD_ARG;
+    if (team < 1) team = 1;
+    if (!ws || ws_bytes < dl_workspace_bytes(B, team) || (reinterpret_cast<uintptr_t>(ws) & 15u) != 0) return DL_ERR_BAD_ARG;
+    if (team > 1 && team > dl_team_max(B)) return DL_ERR_BAD_ARG;    // every workgroup of every team must be resident at once
+    out->grid = fc_grid(B, team);
+    out->hsave = static_cast<float*>(ws);
+    out->rows = nullptr; out->flags = nullptr;
+    if (team > 1) {
+        char* p = static_cast<char*>(ws) + hsave_bytes(B, team);
+        out->rows = reinterpret_cast<float*>(p);
+        out->flags = reinterpret_cast<unsigned*>(p + team_rows_bytes(B));
+        if (!hip_ok(hipMemsetAsync(out->flags, 0, size_t(B) * TEAM_MAX * sizeof(unsigned), stream))) return DL_ERR_HIP;
+    }
     return DL_OK;
 }
 
 int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
                                 const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
-                                int32_t team, void* team_ws, size_t team_ws_bytes, void* stream) {
+                                int32_t team, void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !xh || !t || !node_mask || !out || !nan_flags || B < 0 || N < 1) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
     if (B == 0) return DL_OK;
@@ -1840,21 +2701,18 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
     a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
     a.t_stride = t_is_scalar ? 0 : 1; a.node_mask = node_mask; a.linker_mask = linker_mask;
     a.edge_mask = edge_mask; a.context = context; a.out = out; a.nan_flags = nan_flags; a.prof = g_prof_buf;
-    a.team = 1; a.team_rows = nullptr; a.team_flags = nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    FcWorkspace ws;
+    const int32_t rc = fc_workspace(B, team, workspace, workspace_bytes, st, &ws);
+    if (rc != DL_OK) return rc;
+    a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave;
     const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
     if (team <= 1) {
-        if (!(a.hsave = ensure_hsave(m, B))) return DL_ERR_ALLOC;
-        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, false>), dim3(B), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, false>), dim3(B), dim3(THREADS), 0, st, a);
+        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel2<1>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((egnn_forward_fc_kernel2<0>), dim3(ws.grid), dim3(THREADS), 0, st, a);
     } else {
-        int grid = 0;
-        const int32_t rc = team_prepare(B, team, team_ws, team_ws_bytes, st, &a.team_rows, &a.team_flags, &grid);
-        if (rc != DL_OK) return rc;
-        a.team = team;
-        if (!(a.hsave = ensure_hsave(m, grid))) return DL_ERR_ALLOC;
-        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, true>), dim3(grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, true>), dim3(grid), dim3(THREADS), 0, st, a);
+        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
     }
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
@@ -1862,9 +2720,9 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
 int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
                            int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
                            const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
-                           void* stream) {
+                           void* workspace, size_t workspace_bytes, void* stream) {
     return dl_egnn_forward_fc_team(m, B, N, xh, t, t_is_scalar, node_mask, linker_mask, edge_mask, context, out, nan_flags,
-                                   1, nullptr, 0, stream);
+                                   1, workspace, workspace_bytes, stream);
 }
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stream) {
@@ -1877,21 +2735,19 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if (g->B == 0) return DL_OK;
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
-    a.team_rows = nullptr; a.team_flags = nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    FcWorkspace ws;
+    const int32_t rc = fc_workspace(g->B, g->team, g->workspace, g->workspace_bytes, st, &ws);
+    if (rc != DL_OK) return rc;
+    a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave;
     const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
     if (g->team <= 1) {
         a.a.team = 1;
-        if (!(a.hsave = ensure_hsave(m, g->B))) return DL_ERR_ALLOC;
-        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, false>), dim3(g->B), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, false>), dim3(g->B), dim3(THREADS), 0, st, a);
+        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel2<1>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((sample_chain_fc_kernel2<0>), dim3(ws.grid), dim3(THREADS), 0, st, a);
     } else {
-        int grid = 0;
-        const int32_t rc = team_prepare(g->B, g->team, g->team_ws, g->team_ws_bytes, st, &a.team_rows, &a.team_flags, &grid);
-        if (rc != DL_OK) return rc;
-        if (!(a.hsave = ensure_hsave(m, grid))) return DL_ERR_ALLOC;
-        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, true>), dim3(grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, true>), dim3(grid), dim3(THREADS), 0, st, a);
+        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
     }
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }

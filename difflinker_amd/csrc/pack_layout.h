@@ -9,8 +9,6 @@ struct dl_model {
     dl_config cfg;
     float* d_pack;
     size_t n_floats;
-    float* d_hsave;                 // egnn_fc.hip: per-workgroup node-feature rows across the GCL pair loops
-    size_t hsave_slots;
 };
 
 namespace {
@@ -33,13 +31,14 @@ constexpr int OFF_BLOCKS = OFF_OUT_B + 16;
 // MFMA rows), W2' again as the LDS image of the LDS-resident kernels (features are the MFMA rows, see egnn_fc.hip), vectors
 constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 = 4 * UNIT, G_W2 = 5 * UNIT, G_W2T = 6 * UNIT;
 constexpr int G_VEC = 7 * UNIT;                       // b1', wr', wd', b2', b3', b4, w_att'   (7 x 128)
-constexpr int G_SCALE = G_VEC + 7 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max, b_att
-constexpr int GCL_SIZE = 7 * UNIT + 7 * HID + 12;
+constexpr int G_SCALE = G_VEC + 7 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max, b_att, -, -, -,
+                                                     // [12..19] row L1 norms of W1a',W1b',W3a',W3b',W4', max |b1'|,|b3'|,|b4| (egnn_fc.hip)
+constexpr int GCL_SIZE = 7 * UNIT + 7 * HID + 24;
 // equivariant update: units W5a', W5b', W6' (both LDS images), vectors
 constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT, E_W6T = 3 * UNIT;
 constexpr int E_VEC = 4 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
-constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max
-constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + 8;
+constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max, L1(W5a'), L1(W5b'), max |b5'|
+constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + 16;
 constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
 
 struct ModelDims {

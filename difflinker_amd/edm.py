@@ -333,8 +333,8 @@ class EDM(torch.nn.Module):
         flags = torch.zeros(bs, dtype=torch.int32, device=dev)
         steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
         # a batch smaller than the chip: several compute units per molecule (Dynamics.team)
-        team = self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)))
-        team_ws, team_bytes = self.dynamics.team_workspace(bs, dev) if team > 1 else (None, 0)
+        team = self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)), dev)
+        ws, ws_bytes = self.dynamics.workspace(bs, team, dev)
         args = _lib.DLChainArgs(
             B=bs, N=n, T=T, keep_frames=keep_frames,
             x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
@@ -345,7 +345,7 @@ class EDM(torch.nn.Module):
             inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
             norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
             chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr(), order=order.data_ptr(),
-            team_ws=team_ws.data_ptr() if team_ws is not None else None, team_ws_bytes=team_bytes,
+            workspace=ws.data_ptr(), workspace_bytes=ws_bytes,
             mol_index=mol_index.data_ptr() if mol_index is not None else None)
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)

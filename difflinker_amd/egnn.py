@@ -209,7 +209,7 @@ class Dynamics(nn.Module):
         # fp32 rounding (an atom's messages are summed in a team-size dependent order) and are bitwise repeatable for a
         # given one: pin it when a batch must give identical bits however it is split.
         self.team = os.environ.get('DIFFLINKER_TEAM', 'auto')
-        self._team_ws = None
+        self._fc_ws = None
         self._team_auto = {}
 
     # ---- packed weights -----------------------------------------------------------------------------
@@ -345,8 +345,8 @@ class Dynamics(nn.Module):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if not large:
-                team = self.team_for(bs)
-                ws, need = self.team_workspace(bs, dev) if team > 1 else (None, 0)
+                team = self.team_for(bs, dev)
+                ws, need = self.workspace(bs, team, dev)
                 _lib.check(lib.dl_egnn_forward_fc_team(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
                                                        _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
                                                        _lib.ptr(out), _lib.ptr(flags), team, _lib.ptr(ws), need,
@@ -364,24 +364,34 @@ class Dynamics(nn.Module):
                                                         ctypes.c_void_p(stream)), 'dl_egnn_forward_fc_large')
         return out, flags
 
-    def team_for(self, batch_size):
-        """Workgroups (compute units) per molecule for a batch of ``batch_size``: ``self.team``, 'auto' = ``dl_team_max``."""
+    def team_for(self, batch_size, device=None):
+        """Workgroups (compute units) per molecule for a batch of ``batch_size``: ``self.team``, 'auto' = ``dl_team_max``
+        (a property of the device: asked once per device and batch size)."""
         if self.team in ('auto', None):
-            key = int(batch_size)
-            if key not in self._team_auto:                        # a property of the device: asked once per batch size
-                self._team_auto[key] = int(_lib.load().dl_team_max(key))
+            if device is not None and device.index is not None:
+                index = device.index
+            else:
+                index = torch.cuda.current_device() if torch.cuda.is_available() else -1
+            key = (index, int(batch_size))
+            if key not in self._team_auto:
+                if index >= 0:
+                    with torch.cuda.device(index):
+                        self._team_auto[key] = int(_lib.load().dl_team_max(int(batch_size)))
+                else:                                              # no device: a query, answers 1
+                    self._team_auto[key] = int(_lib.load().dl_team_max(int(batch_size)))
             return self._team_auto[key]
         team = int(self.team)
         if team not in (1, 2, 4, 8):
             raise ValueError(f'Dynamics.team must be "auto", 1, 2, 4 or 8, not {self.team!r}')
         return team
 
-    def team_workspace(self, batch_size, device):
-        """Exchange buffer of the team kernels (``dl_team_workspace_bytes``), cached per model."""
-        need = int(_lib.load().dl_team_workspace_bytes(int(batch_size)))
-        ws = self._team_ws
+    def workspace(self, batch_size, team, device):
+        """Caller-owned scratch of the fully-connected entry points (``dl_workspace_bytes``), cached per model; launches of
+        one model are ordered on the current stream, so one buffer serves them all."""
+        need = int(_lib.load().dl_workspace_bytes(int(batch_size), int(team)))
+        ws = self._fc_ws
         if ws is None or ws.numel() < need or ws.device != device:
-            ws = self._team_ws = torch.empty(need, dtype=torch.uint8, device=device)
+            ws = self._fc_ws = torch.empty(need, dtype=torch.uint8, device=device)
         return ws, need
 
     def _raise_on_flags(self, flags):

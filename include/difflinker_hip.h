@@ -19,7 +19,8 @@
  *   dl_sample_chain_fc                   <- EDM.sample_chain                  src/edm.py:126-176
  *                                           (+ :178-208 reverse step, :210-242 final decode,
  *                                            :328-361 noise / (un)normalisation)
- *   dl_egnn_forward_fc_team, dl_team_max, dl_team_workspace_bytes
+ *   dl_workspace_bytes                   <- (no reference counterpart) scratch the fully-connected entry points need
+ *   dl_egnn_forward_fc_team, dl_team_max
  *                                        <- the same Dynamics.forward / EDM.sample_chain with several compute
  *                                           units per molecule (batches smaller than the chip; no reference
  *                                           counterpart: a launch-geometry knob, results agree to fp32 rounding)
@@ -31,12 +32,13 @@
  *
  * Conventions
  *   - every pointer marked "device" is a HIP device pointer owned by the caller (PyTorch-ROCm
- *     tensors' data_ptr()); the library allocates nothing per call; `stream` is a hipStream_t
- *     passed as void* (0 = default stream); calls are asynchronous on that stream.
- *   - a dl_model owns, besides the packed weights, one scratch buffer (the node features of every workgroup across the
- *     pair loops, 28 KB per workgroup) that grows - with a device synchronisation - the first time a launch needs more
- *     workgroups than any before it; calls that share a dl_model must therefore be ordered (one stream), two models
- *     are independent.
+ *     tensors' data_ptr()); `stream` is a hipStream_t passed as void* (0 = default stream); calls are
+ *     asynchronous on that stream.
+ *   - the library allocates NOTHING after dl_model_create (which uploads the packed weights): every compute entry
+ *     point takes its scratch memory from the caller - `workspace` / `workspace_bytes`, sized by the matching
+ *     dl_*_workspace_bytes query, 16-byte aligned, contents irrelevant on entry, free to reuse once the launch has
+ *     completed on `stream`.  Two launches that run concurrently need two workspaces; a dl_model itself is
+ *     immutable after creation and may be shared by any number of streams.
  *   - all floating point is fp32; masks are int8 (node_mask, edge_mask) or fp32 (fragment /
  *     linker masks, context) exactly as the reference's collate produces them.
  *   - return value: 0 on success, a negative dl_status otherwise; dl_error_string() names it.
@@ -53,7 +55,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 5
+#define DL_ABI_VERSION 6
 
 typedef enum dl_status {
     DL_OK = 0,
@@ -133,7 +135,13 @@ int32_t dl_max_atoms(void);
 int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
                            const float* xh, const float* t, int32_t t_is_scalar,
                            const int8_t* node_mask, const float* linker_mask, const int8_t* edge_mask,
-                           const float* context, float* out, int32_t* nan_flags, void* stream);
+                           const float* context, float* out, int32_t* nan_flags,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* Scratch of dl_egnn_forward_fc / dl_egnn_forward_fc_team / dl_sample_chain_fc for a batch of B molecules with `team`
+ * compute units per molecule (0 or 1: one): per workgroup the fp32 node-feature rows and the pre-computed half of the
+ * node MLP that cross the O(n^2) edge passes through L2 (61 KB), plus, for team > 1, the exchange rows and arrival words. */
+size_t dl_workspace_bytes(int32_t B, int32_t team);
 
 /* DynamicsWithPockets.forward (src/egnn.py:470-552): radius graph rebuilt on the GPU every call
  * (ligand-ligand fully connected, pocket-pocket <= 4 A, ligand-pocket <= 10 A [4 A for 'FC-4A'], everything
@@ -205,8 +213,8 @@ typedef struct dl_chain_args {
                                  * compute unit for the whole chain and workgroups are dispatched in index order, so a
                                  * batch larger than the chip finishes sooner when the big molecules go first
                                  * (longest-processing-time order); results are written at the molecule's own index. */
-    void* team_ws;              /* device scratch of dl_team_workspace_bytes(B) bytes, 16-byte aligned (team > 1 only) */
-    size_t team_ws_bytes;
+    void* workspace;            /* device scratch of dl_workspace_bytes(B, team) bytes, 16-byte aligned */
+    size_t workspace_bytes;
     const int32_t* mol_index;   /* device [B] or NULL: entry b of this batch is molecule mol_offset + mol_index[b] of the
                                  * logical batch (NULL: mol_offset + b) - the key of the in-kernel noise; lets a caller
                                  * sample a non-contiguous part of a batch (e.g. only the molecules that fit this kernel) */
@@ -217,19 +225,18 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* s
 /* Teams: a batch smaller than the chip leaves compute units idle when every molecule sits on one of them (the reference's
  * default sampling batch is 64, generate.py:145).  With team = 2, 4 or 8 that many workgroups share a molecule: each keeps the
  * whole molecule in LDS and repeats the per-atom phases, the O(n^2) pair loop is split by receiving atom and the message
- * sums are exchanged once per pass through `team_ws` (release / acquire hand-off inside the launch, placement-independent).
+ * sums are exchanged once per pass through the workspace (release / acquire hand-off inside the launch, placement-independent).
  * All team * ceil(B / 8) * 8 workgroups must be resident at once: dl_team_max(B) is the largest team the current device
  * holds for a batch of B (1, 2, 4 or 8); a larger request returns DL_ERR_BAD_ARG.  Results agree with team = 1 to fp32
  * rounding (the order in which an atom's messages are summed depends on the team size) and are bitwise repeatable for a
  * given team size.  nan_flags bit 3: a team member did not show up within the spin limit (another kernel held its
  * compute unit for seconds); the sample is void. */
-size_t dl_team_workspace_bytes(int32_t B);
 int32_t dl_team_max(int32_t B);
 /* dl_egnn_forward_fc with a team per molecule (team = 1: identical to dl_egnn_forward_fc) */
 int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,
                                 const int8_t* edge_mask, const float* context, float* out, int32_t* nan_flags,
-                                int32_t team, void* team_ws, size_t team_ws_bytes, void* stream);
+                                int32_t team, void* workspace, size_t workspace_bytes, void* stream);
 
 /* One step of InpaintingEDM.sample_chain after the denoiser call (src/edm.py:568-596), or its final decode
  * (:599-610, :674-713), for one batch: the linker atoms take the p(z_s|z_t) sample, the fragment atoms are re-drawn from

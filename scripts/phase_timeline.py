@@ -70,7 +70,9 @@ names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: b
          (21, 22): 'gcl: barrier (partials read)', (22, 23): 'gcl: h rows + W2\' DMA issue, agg store, max', (23, 25): 'gcl: wait for the h rows (LDS-DMA)', (25, 14): 'gcl: barrier (h, agg in place)', (20, 23): 'gcl: team exchange', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
          (16, 10): 'gcl: end barrier', (16, 30): 'gcl: end barrier', (30, 31): 'eq: stage+proj', (31, 32): 'eq: barrier',
          (32, 33): 'eq: PAIR loop + partials', (33, 34): 'eq: reduce + x', (34, 10): 'eq: end barrier', (34, 3): 'eq: end barrier',
-         (2, 10): 'h->regs', (3, 4): 'output head'}
+         (2, 10): 'h->regs', (3, 4): 'output head', (14, 104): 'gcl: mlp1 frags+gemm(h)', (104, 105): 'gcl: mlp1 image DMA issue + gemm(agg)',
+         (105, 15): 'gcl: mlp1 epilogue', (14, 105): 'gcl: mlp1 frags + both gemms', (15, 106): 'gcl: barrier + mlp2 residual loads', (106, 107): 'gcl: mlp2 gemm',
+         (107, 16): 'gcl: mlp2 epilogue (LDS + HBM rows)', (22, 23): 'gcl: W2\' DMA issue + agg fragment rows', (23, 14): 'gcl: barrier (agg in place)'}
 inloop = {(40, 41): 'L1 (geo, SiLU, split)', (41, 42): 'M0 (48 mfma)', (42, 43): 'E0 (epilogue)', (43, 44): 'M1 (48 mfma)',
           (44, 45): 'E1 (epilogue)'}
 for w in range(8):
@@ -79,7 +81,7 @@ for w in range(8):
     tags = [int(x) for x in e[:n, 0]]
     ts = [int(x) for x in e[:n, 1]]
     # pass-level events only (tags < 40), in-loop events (40..45) of step 2 reported separately per pass kind
-    top = [(tg, t_) for tg, t_ in zip(tags, ts) if tg < 40]
+    top = [(tg, t_) for tg, t_ in zip(tags, ts) if tg < 40 or tg >= 100]
     tot = collections.OrderedDict()
     for k in range(len(top) - 1):
         nm = names.get((top[k][0], top[k + 1][0]), str((top[k][0], top[k + 1][0])))
@@ -95,7 +97,7 @@ for w in range(8):
         if key in inloop:
             loop[kind][inloop[key]] = loop[kind].get(inloop[key], 0) + ts[k + 1] - ts[k]
             if key == (40, 41): cnt[kind] += 1
-    segs = [(tg, t_) for tg, t_ in zip(tags, ts) if tg >= 40]
+    segs = [(tg, t_) for tg, t_ in zip(tags, ts) if 40 <= tg < 100]
     if segs and w in (0, 4):
         # ping-pong builds: (40+k) = segment k of steps 2..3 finished, (60+k) = barrier k released; first pass only
         first = []

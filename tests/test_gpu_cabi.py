@@ -37,7 +37,9 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
         out = torch.full((B, N, 3 + nf), float('nan'), device=d)
         flags = torch.full((B,), -1, dtype=torch.int32, device=d)
         p = lambda x: ctypes.c_void_p(x.data_ptr())          # noqa: E731
-        st = lib.dl_egnn_forward_fc(model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None)
+        need = lib.dl_workspace_bytes(B, 1)                  # ABI v6: the caller owns the scratch, the callee allocates nothing
+        ws = torch.empty(need, dtype=torch.uint8, device=d)
+        st = lib.dl_egnn_forward_fc(model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), p(ws), need, None)
         assert st == 0
         torch.cuda.synchronize()
         ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
@@ -50,9 +52,9 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
         assert max(0.0, dv - floor) / float(ref[..., :3].double().norm()) <= 2e-5
         assert float(out.cpu()[..., :3].abs().max()) > 0
         # status codes: null pointer, negative batch, a molecule with more atoms than dl_max_atoms() (flag bit 2)
-        assert lib.dl_egnn_forward_fc(model, B, N, None, p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == -1
-        assert lib.dl_egnn_forward_fc(model, -1, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == -1
-        assert lib.dl_egnn_forward_fc(model, 0, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), None) == 0
+        assert lib.dl_egnn_forward_fc(model, B, N, None, p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), p(ws), need, None) == -1
+        assert lib.dl_egnn_forward_fc(model, -1, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), p(ws), need, None) == -1
+        assert lib.dl_egnn_forward_fc(model, 0, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), p(ws), need, None) == 0
         big, zb, tb = ragged_inputs([56], [3], nf, seed=6)
         xb = zb.to(d).contiguous()
         nmb = big['node_mask'].reshape(1, 56).to(torch.int8).to(d).contiguous()
@@ -61,7 +63,7 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
         cxb = big['context'].reshape(1, 56, ctx).float().to(d).contiguous()
         outb = torch.empty((1, 56, 3 + nf), device=d)
         fb = torch.zeros((1,), dtype=torch.int32, device=d)
-        assert lib.dl_egnn_forward_fc(model, 1, 56, p(xb), p(tb.to(d)), 0, p(nmb), p(lmb), p(emb), p(cxb), p(outb), p(fb), None) == 0
+        assert lib.dl_egnn_forward_fc(model, 1, 56, p(xb), p(tb.to(d)), 0, p(nmb), p(lmb), p(emb), p(cxb), p(outb), p(fb), p(ws), need, None) == 0
         torch.cuda.synchronize()
         assert int(fb.cpu()[0]) & 4 and float(outb.abs().max()) == 0.0
     finally:
@@ -72,7 +74,7 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
 
 
 def test_team_entry_points_through_raw_ctypes():
-    """ABI v5: dl_egnn_forward_fc_team / dl_team_max / dl_team_workspace_bytes without the Python drop-in: same numbers as
+    """ABI v6: dl_egnn_forward_fc_team / dl_team_max / dl_workspace_bytes without the Python drop-in: same numbers as
     the one-workgroup entry point to fp32 rounding, documented refusals (team size, workspace size and alignment)."""
     from difflinker_amd import _lib
     from difflinker_amd.egnn import egnn_tensor_order
@@ -95,14 +97,14 @@ def test_team_entry_points_through_raw_ctypes():
         cx = inp['context'].reshape(B, N, ctx).float().to(d).contiguous()
         p = lambda x: ctypes.c_void_p(x.data_ptr())          # noqa: E731
         assert lib.dl_team_max(B) == 8
-        need = lib.dl_team_workspace_bytes(B)
+        need = max(lib.dl_workspace_bytes(B, team) for team in (1, 2, 4, 8))
         ws = torch.empty(need + 16, dtype=torch.uint8, device=d)
         outs = {}
         for team in (1, 2, 4, 8):
             out = torch.full((B, N, 3 + nf), float('nan'), device=d)
             flags = torch.full((B,), -1, dtype=torch.int32, device=d)
             st = lib.dl_egnn_forward_fc_team(model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags),
-                                             team, p(ws), need, None)
+                                             team, p(ws), lib.dl_workspace_bytes(B, team), None)
             torch.cuda.synchronize()
             assert st == 0 and flags.cpu().tolist() == [0] * B
             outs[team] = out.cpu()
@@ -113,11 +115,15 @@ def test_team_entry_points_through_raw_ctypes():
         out = torch.empty((B, N, 3 + nf), device=d)
         flags = torch.zeros((B,), dtype=torch.int32, device=d)
         args = (model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags))
+        need4, need1 = lib.dl_workspace_bytes(B, 4), lib.dl_workspace_bytes(B, 1)
         assert lib.dl_egnn_forward_fc_team(*args, 3, p(ws), need, None) == -1                 # team must be 1, 2, 4 or 8
-        assert lib.dl_egnn_forward_fc_team(*args, 4, p(ws), need - 1, None) == -1             # workspace too small
-        assert lib.dl_egnn_forward_fc_team(*args, 4, None, need, None) == -1                  # no workspace
-        assert lib.dl_egnn_forward_fc_team(*args, 4, ctypes.c_void_p(ws.data_ptr() + 4), need, None) == -1   # not 16-byte aligned
-        assert lib.dl_egnn_forward_fc_team(*args, 1, None, 0, None) == 0                      # team 1 needs none
+        assert lib.dl_egnn_forward_fc_team(*args, 4, p(ws), need4 - 1, None) == -1            # workspace too small
+        assert lib.dl_egnn_forward_fc_team(*args, 4, None, need4, None) == -1                 # no workspace
+        assert lib.dl_egnn_forward_fc_team(*args, 4, ctypes.c_void_p(ws.data_ptr() + 4), need4, None) == -1   # not 16-byte aligned
+        assert lib.dl_egnn_forward_fc_team(*args, 1, None, 0, None) == -1                     # ABI v6: team 1 needs its scratch too
+        assert lib.dl_egnn_forward_fc(*args, p(ws), need1 - 1, None) == -1
+        assert lib.dl_egnn_forward_fc(*args, p(ws), need1, None) == 0                         # the callee allocates nothing
         torch.cuda.synchronize()
+        assert flags.cpu().tolist() == [0] * B and rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= 2e-5
     finally:
         lib.dl_model_destroy(model)

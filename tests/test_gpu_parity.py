@@ -30,6 +30,13 @@ def dev():
     return torch.device('cuda:0')
 
 
+@pytest.fixture(params=['1', 'auto'], autouse=True)
+def compute_units_per_molecule(request, monkeypatch):
+    """Every case of this file runs twice: on one compute unit per molecule (the kernels of batches >= 256, i.e. of the
+    benchmark) and with Dynamics.team = 'auto' (teams of 8 workgroups per molecule at these small batches)."""
+    monkeypatch.setenv('DIFFLINKER_TEAM', request.param)
+
+
 def make_dynamics(nf, ctx, n_layers, seed, coord_gain=0.02, precision=None):
     from difflinker_amd import Dynamics
     dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, n_layers=n_layers,

@@ -113,7 +113,7 @@ def test_team_requests_the_device_cannot_hold_are_refused():
     lib = _lib.load()
     assert lib.dl_team_max(8) == 8 and lib.dl_team_max(32) == 8 and lib.dl_team_max(33) == 4 and lib.dl_team_max(64) == 4
     assert lib.dl_team_max(65) == 2 and lib.dl_team_max(128) == 2 and lib.dl_team_max(256) == 1
-    assert lib.dl_team_workspace_bytes(0) == 0 and lib.dl_team_workspace_bytes(3) == 3 * (2 * 55 * 128 * 4 + 32)
+    assert lib.dl_workspace_bytes(0, 4) == 0 and lib.dl_workspace_bytes(3, 4) > lib.dl_workspace_bytes(3, 2) > lib.dl_workspace_bytes(3, 1) > 0
     nf = 9
     dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=5)
     inp, z, t = ragged_inputs([10] * 70, [3] * 70, nf, seed=6)          # 70 molecules: 72 slots x 4 > 256 compute units

@@ -26,10 +26,15 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dl_abi_version() == _lib.ABI_VERSION == 5
-    assert lib.dl_team_workspace_bytes(2) == 2 * (2 * 55 * 128 * 4 + 8 * 4)       # exchange rows + arrival words
+    assert lib.dl_abi_version() == _lib.ABI_VERSION == 6
+    # the caller-owned scratch (ABI v6): a size query, no device needed; nothing for an empty batch, linear in the batch,
+    # a team adds its exchange rows and arrival words on top of one h-row block per workgroup
+    w1, w2 = lib.dl_workspace_bytes(1, 1), lib.dl_workspace_bytes(2, 1)
+    assert lib.dl_workspace_bytes(0, 1) == 0 and w1 > 0 and w2 == 2 * w1 and w1 % 16 == 0
+    assert lib.dl_workspace_bytes(8, 0) == lib.dl_workspace_bytes(8, 1) == 8 * w1
+    assert lib.dl_workspace_bytes(8, 4) > 4 * lib.dl_workspace_bytes(8, 1) and lib.dl_workspace_bytes(8, 3) >= 0
     assert lib.dl_team_max(64) in (1, 2, 4, 8) and lib.dl_team_max(0) == 1         # 1 without a device (a query, not a compute call)
-    assert ctypes.sizeof(_lib.DLChainArgs) == 192                                   # dl_chain_args of ABI v5 (LP64)
+    assert ctypes.sizeof(_lib.DLChainArgs) == 192                                   # dl_chain_args of ABI v5 / v6 (LP64)
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
     cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
