@@ -68,7 +68,7 @@ EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_stri
            'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
            'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
            'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large', 'dl_inpaint_step', 'dl_workspace_bytes',
-           'dl_team_max', 'dl_egnn_forward_fc_team')
+           'dl_team_max', 'dl_egnn_forward_fc_team', 'dl_team_max_atoms', 'dl_debug_team_fault')
 
 _lib = None
 
@@ -110,6 +110,10 @@ def load():
     lib.dl_workspace_bytes.argtypes = [i32, i32]
     lib.dl_team_max.restype = i32
     lib.dl_team_max.argtypes = [i32]
+    lib.dl_team_max_atoms.restype = i32
+    lib.dl_team_max_atoms.argtypes = [i32]
+    lib.dl_debug_team_fault.restype = None
+    lib.dl_debug_team_fault.argtypes = [i32]
     lib.dl_sampler_step.restype = i32
     lib.dl_sampler_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, DLStepCoef, vp, vp]
     lib.dl_set_profile_buffer.restype = None

@@ -36,39 +36,37 @@
 namespace {
 
 constexpr int LDH = 132;            // LDS row stride of [n,128] fp32 tiles: 528 B = 33 x 16 B (conflict-free b128)
-constexpr int NMAX = 55;            // real atoms per molecule that fit the LDS-resident layout
-// Workgroup = 8 waves = two per SIMD: they own the 2 x 4 grid of 32x32 output tiles of every per-node GEMM (and the
-// matching register tile of h) and 32 pair slots each in the pair passes.  (A third wave per SIMD - a 768-thread build
-// with helper waves - measured equal in round 1 and does not fit the register budget of the pair loop: removed.)
+constexpr int NMAX = 55;            // atoms OWNED by one workgroup: rows of P, of the h / agg / hidden fragment rows, of z
+constexpr int NQMAX = 2 * NMAX;     // atoms of one molecule in a TEAM of workgroups: sender rows Q, coordinates, compaction index
+// Workgroup = 8 waves = two per SIMD: they own the 2 x 4 grid of 32x32 output tiles of every per-node GEMM and 32 pair slots
+// each in the pair passes.
 constexpr int THREADS = 512;
 constexpr int NWAVES = THREADS / 64;
 constexpr int GWAVES = 8;
 constexpr int GTHREADS = 64 * GWAVES;
 // ---- LDS layout (floats) ---------------------------------------------------------------------------
-constexpr int L_A = 0;                                // P  / h row-major / eps (aliased at the end)
-constexpr int L_B = L_A + NMAX * LDH;                 // Q  / node-MLP hidden
-constexpr int L_C = L_B + NMAX * LDH;                 // H (node features) / message aggregate
+constexpr int L_A = 0;                                // P (own atoms) / eps (aliased at the end)
+constexpr int L_B = L_A + NMAX * LDH;                 // Q (one workgroup per molecule: <= 55 rows; a team: all atoms, up to 110
+constexpr int L_C = L_B + NMAX * LDH;                 //    rows through L_C) / node-MLP hidden | h fragment rows / message aggregate
 constexpr int L_W = L_C + NMAX * LDH;                 // 128x128 second-layer weights, [k][c][nt]
 constexpr int L_VEC = L_W + UNIT;                     // wr', wd', b2'|b6', w7'
-constexpr int L_XS = L_VEC + 4 * HID;                 // current coordinates [n][4]
-constexpr int L_X0 = L_XS + NMAX * 4;                 // coordinates at forward entry [n][4]
-constexpr int L_AGGX = L_X0 + NMAX * 4;               // coordinate aggregate [n][4]
-constexpr int L_Z = L_AGGX + NMAX * 4;                // per-atom state z [n][DMAX]
-constexpr int L_LM = L_Z + NMAX * DMAX;               // linker mask [n]
-constexpr int L_FRAG = L_LM + 56;                     // fragment mask [n]
-constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padded position [n] (int)
-constexpr int L_RCV = L_IDX + 56;                     // coordinate-pass receivers: list position -> atom [n] (int)
-constexpr int L_RPOS = L_RCV + 56;                    // atom -> position in that list, -1: not a receiver [n] (int)
-constexpr int L_CTX = L_RPOS + 56;                    // context [n][CTXMAX]
-constexpr int L_MISC = L_CTX + NMAX * CTXMAX;         // ints: [0] n_b, [1] nan bits, [2..11] team block (TM_*)
-constexpr int MISC_WORDS = 40;                        // [0..15] as listed, [16..39] the pass context (CX_*, per-atom phases v2)
+constexpr int L_XS = L_VEC + 4 * HID;                 // current coordinates of every atom of the molecule [n][4]
+constexpr int L_X0 = L_XS + NQMAX * 4;                // coordinates at forward entry [n][4]
+constexpr int L_Z = L_X0 + NQMAX * 4;                 // per-atom state z of the own atoms [n_own][DMAX]
+constexpr int L_LM = L_Z + NMAX * DMAX;               // linker mask of the own atoms
+constexpr int L_FRAG = L_LM + 56;                     // fragment mask of the own atoms
+constexpr int L_IDX = L_FRAG + 56;                    // compacted atom -> padded position, every atom of the molecule (int)
+constexpr int L_RCV = L_IDX + 112;                    // coordinate-pass receivers: list position -> own atom (int)
+constexpr int L_RPOS = L_RCV + 56;                    // own atom -> position in that list, -1: not a receiver (int)
+constexpr int L_MISC = L_RPOS + 56;                   // ints: [0] n_b, [1] nan bits, [2..15] team block (TM_*), [16..] pass context (CX_*)
+constexpr int MISC_WORDS = 40;
 constexpr int L_FMAX = L_MISC + MISC_WORDS;           // f16x3 magnitude bounds (float bits, atomicMax)
-constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_b (branch-free)
+constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_own (branch-free)
 constexpr int L_TOTAL = L_DUMMY + LDH;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
-              (L_X0 % 4) == 0 && (L_AGGX % 4) == 0 && (L_Z % 4) == 0 && (L_CTX % 4) == 0 && (L_DUMMY % 4) == 0, "16-byte alignment");
+              (L_X0 % 4) == 0 && (L_Z % 4) == 0 && (L_DUMMY % 4) == 0, "16-byte alignment");
 
 // Team kernels (several workgroups share one molecule, see team_sync): words of v.misc.  Everything a team member needs
 // is re-read from here at the point of use, so nothing of it lives in registers across the pair loops.
@@ -76,11 +74,11 @@ constexpr int TM_EPOCH = 2;      // exchanges completed so far
 constexpr int TM_FAIL = 3;       // a team-mate did not show up in time
 constexpr int TM_ROWS = 4;       // exchange rows of this molecule (device pointer: lo, hi)
 constexpr int TM_FLAGS = 6;      // arrival words of this molecule's workgroups (device pointer: lo, hi)
-constexpr int TM_S = 8, TM_RANK = 9, TM_R0 = 10, TM_NREC = 11;   // team size, own index, own receivers [r0, r0 + nrec)
+constexpr int TM_S = 8, TM_RANK = 9, TM_NOWN = 10, TM_XSLOT = 11;   // team size, own index, number of own atoms (one workgroup: 1, 0, n_b), current max |x|^2 slot
 constexpr int MS_NRCV = 12;      // (every kernel) length of the coordinate-pass receiver list v.rcv
 
 struct Lds {
-    float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag, *ctx;
+    float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag;
     int *idx, *rcv, *rpos, *misc;
     unsigned* fmax;
     float* dummy;
@@ -89,8 +87,9 @@ struct Lds {
 __device__ __forceinline__ Lds lds_view(float* base) {
     Lds v;
     v.A = base + L_A; v.B = base + L_B; v.C = base + L_C; v.W = base + L_W; v.vec = base + L_VEC;
-    v.xs = base + L_XS; v.x0 = base + L_X0; v.aggx = base + L_AGGX; v.z = base + L_Z;
-    v.lm = base + L_LM; v.frag = base + L_FRAG; v.ctx = base + L_CTX;
+    v.xs = base + L_XS; v.x0 = base + L_X0; v.z = base + L_Z;
+    v.aggx = base + L_B;                       // coordinate aggregate of the own atoms [n_own][4]: over Q, dead once a pair loop is over
+    v.lm = base + L_LM; v.frag = base + L_FRAG;
     v.idx = reinterpret_cast<int*>(base + L_IDX); v.misc = reinterpret_cast<int*>(base + L_MISC);
     v.rcv = reinterpret_cast<int*>(base + L_RCV); v.rpos = reinterpret_cast<int*>(base + L_RPOS);
     v.fmax = reinterpret_cast<unsigned*>(base + L_FMAX);
@@ -158,40 +157,6 @@ __device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
     if (lane == 0) atomicMax(slot, b);
 }
 
-// acc[32 atoms x 32 features] += A[atoms][k] * W'[feature][k],  k = 0..127.  B: pre-loaded fragments.
-// PREC 0 (fp32 MFMA): A = LDS row `arow`, this lane supplies k = 64*hh + s.
-// PREC 1 (f16x3):     this lane supplies k = 16*slab + 8*hh + e; b.q[slab] / b.q[8+slab] = hi / lo parts of the
-//                     pre-scaled weights; `sa` scales A into the fp16 range (acc is in units of sa*sw).
-template <int PREC>
-__device__ __forceinline__ void gemm_k128(floatx16& acc, const float* abuf, int arow, int hh, const BFrag& b,
-                                          float sa) {
-    if constexpr (PREC == 0) {
-        const float4* ap = reinterpret_cast<const float4*>(abuf + arow * LDH + 64 * hh);
-#pragma unroll
-        for (int sg = 0; sg < 16; ++sg) {
-            const float4 a = ap[sg];
-            acc = mfma32(a.x, b.q[sg].x, acc);
-            acc = mfma32(a.y, b.q[sg].y, acc);
-            acc = mfma32(a.z, b.q[sg].z, acc);
-            acc = mfma32(a.w, b.q[sg].w, acc);
-        }
-    } else {
-        const float* ap = abuf + arow * LDH + 8 * hh;
-#pragma unroll
-        for (int slab = 0; slab < 8; ++slab) {
-            const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * slab);
-            const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * slab + 4);
-            const float u[8] = {a0.x * sa, a0.y * sa, a0.z * sa, a0.w * sa, a1.x * sa, a1.y * sa, a1.z * sa, a1.w * sa};
-            uint4 hi, lo;
-            split8(u, hi, lo);
-            const uint4 bh = __builtin_bit_cast(uint4, b.q[slab]), bl = __builtin_bit_cast(uint4, b.q[8 + slab]);
-            acc = mfma_h(lo, bh, acc);
-            acc = mfma_h(hi, bl, acc);
-            acc = mfma_h(hi, bh, acc);
-        }
-    }
-}
-
 // Workgroup barrier for LDS hand-offs that does NOT drain the vector-memory counter (unlike __syncthreads(), whose
 // fence waits for every LDS-DMA and prefetch in flight): own LDS traffic retired, then s_barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -237,26 +202,11 @@ __device__ __forceinline__ LaneIds lane_ids() {
     q.nt = q.w & 3; q.mt = q.w >> 2;
     return q;
 }
-// This wave's projection fragments of a pass, the first thing the pass needs: requested one phase AHEAD (during
-// the previous pass's last node GEMM / the previous coordinate pass's reduction) so the L2/MALL latency is off
-// the critical path.  (The W2' image goes global -> LDS by DMA, stage_dma.)
-struct PreW {
-    BFrag bf;
-};
-__device__ __forceinline__ void load_pre(PreW& pw, const float* __restrict__ unit_a, const float* __restrict__ unit_b,
-                                         int w, int lane) {
-    pw.bf = load_bfrag((w < 4 ? unit_a : unit_b) + (w & 3) * (UNIT / 4), lane);
-}
 // what the NEXT pass needs prefetched (base == nullptr: nothing follows)
 struct NextPass {
     const float* base;
     bool equiv;
 };
-__device__ __forceinline__ void load_next(PreW& pw, const NextPass& nx, int w, int lane) {
-    if (nx.base == nullptr) return;
-    if (nx.equiv) load_pre(pw, nx.base + E_W5A, nx.base + E_W5B, w, lane);
-    else load_pre(pw, nx.base + G_W1A, nx.base + G_W1B, w, lane);
-}
 __device__ __forceinline__ void stage_next(const Lds& v, const NextPass& nx, int w, int tid) {
     if (nx.base == nullptr) return;
     stage_dma(v, nx.base + (nx.equiv ? E_W6T : G_W2T), nx.base + (nx.equiv ? E_VEC : G_VEC) + HID,
@@ -269,38 +219,18 @@ __device__ __forceinline__ void store_row(const Lds& v, float* buf, int row, int
     *p = val;
 }
 
-// P[a][f] = b1'[f] + sum_k W1a'[f][k] H[a][k]  -> v.A ;  Q[a][f] = sum_k W1b'[f][k] H[a][k] -> v.B
-// f16x3: `sa` scales H, `inv` = 1/(sa*sw) rescales the accumulator; returns max |P| or |Q| this lane wrote.
-template <int PREC>
-__device__ __forceinline__ float node_pre(const Lds& v, int nb, int w, int lane, const BFrag& bf, float bias,
-                                          float sa, float inv) {
-    const int c = lane & 31, hh = lane >> 5;
-    const int nt = w & 3;
-    float* dst = (w < 4) ? v.A : v.B;
-    const int mtiles = nb > 32 ? 2 : 1;
-    float vmax = 0.0f;
-    for (int mt = 0; mt < mtiles; ++mt) {
-        floatx16 acc = splat16(PREC == 0 ? bias : 0.0f);
-        const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128<PREC>(acc, v.C, arow, hh, bf, sa);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 32 * mt + acc_row(reg, hh);
-            const float val = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias);
-            store_row(v, dst, row, nb, 32 * nt + c, val);
-            vmax = fmaxf(vmax, row < nb ? fabsf(val) : 0.0f);
-        }
-    }
-    return vmax;
-}
-
 // f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
-constexpr int FM_H0 = 0, FM_H1 = 1, FM_PQ = 2, FM_AGG = 3, FM_T = 4, FM_X2 = 5, FM_X02 = 6;
+constexpr int FM_H0 = 0, FM_H1 = 1, FM_HG = 2, FM_AGG = 3, FM_X2B = 4, FM_X2 = 5, FM_X02 = 6;
+// FM_H0/1: max |h| over the OWN atoms (two slots alternate); FM_HG: over the whole molecule (teams: from the exchange headers);
+// FM_X2 (teams: FM_X2 / FM_X2B alternate, TM_XSLOT names the current one): max |x|^2 over every atom; FM_X02: the same at forward entry
 
 // f16x3: common scale S1 of the rank-2 geometric term (r * wr' and d0 * wd' products in one accumulator); sc[6], sc[7] =
 // max |wr'|, max |wd'|.  The sender rows Q are stored times S1 (node_pre) and enter that MFMA as its C operand.
+template <bool TEAM>
+__device__ __forceinline__ int x2_slot(const Lds& v) { return TEAM ? v.misc[TM_XSLOT] : FM_X2; }
+template <bool TEAM>
 __device__ __forceinline__ float geo_scale(const Lds& v, const float* __restrict__ sc) {
-    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+    const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
     return fminf(scale_for(4.0f * x2) * scale_for(sc[6]), scale_for(4.0f * x02) * scale_for(sc[7]));
 }
 
@@ -357,23 +287,18 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                                            float norm_constant, float sa, float inv_scale, const float* __restrict__ sc,
                                            float head, Prof& pf) {
     const int c = lane & 31, hh = lane >> 5;
-    // receivers of this workgroup.  GCL: every atom (or its share of a team's).  Coordinate head: only the atoms whose
-    // update survives the linker mask - the reference multiplies the sum of every other atom by zero (egnn.py:113-116) -
-    // i.e. the entries of the list v.rcv (or this member's share of them)
-    int r0 = 0, nrec = EQUIV ? v.misc[MS_NRCV] : nb;
-    if constexpr (TEAM) {
-        if (EQUIV) {
-            const int S = v.misc[TM_S], rank = v.misc[TM_RANK];
-            r0 = (nrec * rank) / S;
-            nrec = (nrec * (rank + 1)) / S - r0;
-        } else { r0 = v.misc[TM_R0]; nrec = v.misc[TM_NREC]; }
-    }
+    // receivers of this workgroup: its OWN atoms (one workgroup per molecule: every atom; a team: atoms rank, rank + S, ...).
+    // GCL: all of them.  Coordinate head: only those whose update survives the linker mask - the reference multiplies the sum
+    // of every other atom by zero (egnn.py:113-116) - i.e. the entries of the list v.rcv.  Senders: every atom of the molecule.
+    const int nrec = EQUIV ? v.misc[MS_NRCV] : (TEAM ? v.misc[TM_NOWN] : nb);
+    const int S = TEAM ? v.misc[TM_S] : 1, rank = TEAM ? v.misc[TM_RANK] : 0;
     const SlotPlan pl = slot_plan(nrec, nb);
     const int q = pl.q;
     const int slot = 32 * w + c;
     const bool slot_ok = slot < nrec * pl.g;
     const int il = slot_ok ? slot / pl.g : 0;
-    const int i = EQUIV ? (slot_ok ? v.rcv[r0 + il] : 0) : r0 + il;
+    const int li = EQUIV ? (slot_ok ? v.rcv[il] : 0) : il;        // the receiving atom among the own atoms: its row of P
+    const int i = rank + li * S;                                  // ... and in the molecule: coordinates, row of the edge mask
     const int j0 = slot_ok ? (slot - il * pl.g) * q : 0;
     const int jn = slot_ok ? min(q, nb - j0) : 0;                 // senders this slot really has (may be <= 0)
     const bool wave_active = 32 * w < nrec * pl.g;                // wave-uniform
@@ -388,7 +313,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
         const float4 xi = *reinterpret_cast<const float4*>(v.xs + 4 * i);
         const float4 yi = *reinterpret_cast<const float4*>(v.x0 + 4 * i);
         const int8_t* mrow = emask ? emask + v.idx[i] * N : nullptr;
-        const float* Pp_ = v.A + i * LDH + 4 * hh;
+        const float* Pp_ = v.A + li * LDH + 4 * hh;
         const float* bias_p_ = v.vec + 2 * HID + 4 * hh;
         const float* w7_p_ = v.vec + 3 * HID + 4 * hh;
         const float isa = inv_pow2(sa);
@@ -402,7 +327,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             for (int mt = 0; mt < 4; ++mt) ga[mt] = v.vec[(hh ? HID : 0) + 32 * mt + c];
         } else {
             const float s_wr = scale_for(sc[6]), s_wd = scale_for(sc[7]);
-            const float S1 = geo_scale(v, sc);
+            const float S1 = geo_scale<TEAM>(v, sc);
             invS1 = inv_pow2(S1);
             sX = S1 * inv_pow2(hh ? s_wd : s_wr);
             const float s_w = hh ? s_wd : s_wr;
@@ -724,8 +649,8 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 struct AggRegs {
     float4 v[4];
 };
-__device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, AggRegs& out, float scale) {
-    const SlotPlan pl = slot_plan(nb, nb);
+__device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nown, int nb, int tid, AggRegs& out, float scale) {
+    const SlotPlan pl = slot_plan(nown, nb);
     float am = 0.0f;
     // the four groups of a thread are independent chains: their reads go out together, chunk by chunk (a group past the
     // end of the molecule reads the last atom's rows and is discarded)
@@ -734,7 +659,7 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int e = tid + THREADS * k;
-        src[k] = v.A + min(e >> 5, nb - 1) * pl.g * PB_STRIDE + 4 * (e & 31);
+        src[k] = v.A + max(min(e >> 5, nown - 1), 0) * pl.g * PB_STRIDE + 4 * (e & 31);
         s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int ch = 0; ch < pl.g; ++ch) {
@@ -748,7 +673,7 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, 
     for (int k = 0; k < 4; ++k) {
         const int e = tid + THREADS * k;
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < nb * 32) {
+        if (e < nown * 32) {
             r = make_float4(s[k].x * scale, s[k].y * scale, s[k].z * scale, s[k].w * scale);   // 1, or 1/N for aggregation_method='mean'
             am = fmaxf(fmaxf(am, fmaxf(fabsf(r.x), fabsf(r.y))), fmaxf(fabsf(r.z), fabsf(r.w)));
         }
@@ -756,18 +681,11 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nb, int tid, 
     }
     return am;
 }
-__device__ __forceinline__ void pair_store_gcl(const Lds& v, int nb, int tid, const AggRegs& in) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int e = tid + THREADS * k;
-        if (e < nb * 32) *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = in.v[k];
-    }
-}
 // coordinate head: aggx[i][0..2] = sum of the slot triples of receiver i (thread = atom; atoms off the list keep whatever
 // aggx holds: the update skips them)
-__device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid, float scale) {
+__device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nown, int nb, int tid, float scale) {
     const SlotPlan pl = slot_plan(v.misc[MS_NRCV], nb);
-    const int k = tid < nb ? v.rpos[tid] : -1;
+    const int k = tid < nown ? v.rpos[tid] : -1;
     if (k >= 0) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int ch = 0; ch < pl.g; ++ch) {
@@ -780,20 +698,28 @@ __device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nb, int tid,
 
 
 // ---------------------------------------------------------------------------------------------------
-// Teams: S workgroups (S compute units) share one molecule when the batch is smaller than the chip.  Every member keeps the
-// whole molecule in its LDS and repeats the per-atom phases (projections, node MLP, sampler algebra: identical code on
-// identical data, so the copies stay bitwise equal); the O(n^2) pair loop - three quarters of a forward - is split by
-// RECEIVER: member r owns atoms [n r / S, n (r+1) / S), spreads them over all 256 slots (S times fewer senders per slot,
-// i.e. S times fewer steps) and ends up with the message sums of its atoms only.  Those rows are exchanged once per pass
-// through a small HBM buffer:  write-through (sc1) 16-byte stores -> every storing wave drains -> workgroup barrier -> one
-// lane publishes the exchange number in its arrival word (agent-scope relaxed store) -> one wave polls the S arrival words
-// (relaxed, bounded) -> workgroup barrier -> sc1 loads of ALL rows (the member's own included, so every copy continues from
-// the same bits).  Placement-independent: nothing assumes which XCD a member runs on (MI355X_MICROARCH.md, inter-workgroup
-// visibility).  Two row buffers alternate: a member can be at most one exchange ahead of the slowest one.
-// The launch must keep all S * B workgroups resident at once (one per compute unit): dl_* checks it against the CU count.
+// Teams (version 2): S workgroups (S compute units) share one molecule - when the batch is smaller than the chip, or when
+// the molecule has more atoms than one workgroup's LDS holds.  Atoms are dealt round-robin: member `rank` OWNS atoms rank,
+// rank + S, ... (the linker atoms, which sit together at the end of a molecule, spread over all members).  A member keeps in
+// LDS the state of its own atoms only - z, the h / aggregate / hidden fragment rows, the P rows - and does the per-atom
+// phases (node MLP, projections, sampler algebra) for them alone; its pair loops take its own atoms as receivers and EVERY
+// atom as sender, so it needs the sender rows Q and the coordinates of the whole molecule: once per pass (and never for the
+// message sums, which stay where they are used) every member publishes the Q rows and coordinates of its atoms in a
+// per-molecule HBM buffer and reads everybody's:  16-byte write-through (sc1) stores -> every storing wave drains -> workgroup
+// barrier -> one lane publishes the exchange number in the member's arrival word (agent-scope relaxed store) -> one wave polls
+// the S arrival words (relaxed, bounded) -> workgroup barrier -> sc1 loads.  Placement-independent (MI355X_MICROARCH.md,
+// inter-workgroup visibility); two row buffers alternate, a member is at most one exchange ahead of the slowest one.
+// With Q in the space of two row blocks a team holds molecules of up to NQMAX = 110 atoms.
+// A member that gives up waiting (the launch did not get all its workgroups resident at once) publishes a POISON arrival word:
+// every member that sees it stops waiting too, from then on nobody waits, and every member ends with flag bit 3 - the host
+// re-runs that batch on a path that needs no co-residency.
 constexpr int TEAM_MAX = 8;                                   // arrival words per molecule
-constexpr int TEAM_ROW_BYTES = NMAX * HID * 4;                // one parity of a molecule's exchange rows
+constexpr int TX_ROW = LDH;                                   // exchange row: 128 floats of Q, then x, y, z, 0
+constexpr int TEAM_X_BYTES = 2 * NQMAX * TX_ROW * 4;          // both parities of a molecule's exchange rows
+constexpr int TEAM_HDR_BYTES = 2 * TEAM_MAX * 16;             // per parity and member: max |h| of its atoms (float bits), 3 spare words
+constexpr int TEAM_MOL_BYTES = TEAM_X_BYTES + TEAM_HDR_BYTES;
 constexpr unsigned TEAM_SPIN_LIMIT = 1u << 22;                // polls (~ seconds) before a member gives up
+constexpr unsigned TEAM_POISON = 0xFFFFFFFFu;
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -803,11 +729,10 @@ __device__ __forceinline__ unsigned long long team_ptr(const Lds& v, int word) {
     return (unsigned long long)lo | ((unsigned long long)hi << 32);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t team_rows(const Lds& v) {
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(team_ptr(v, TM_ROWS)), 0, 2 * TEAM_ROW_BYTES, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(team_ptr(v, TM_ROWS)), 0, TEAM_MOL_BYTES, 0x00020000);
 }
 
-// the rows of exchange number `epoch` are stored: publish, wait for the team.  On a timeout the forward goes on with
-// whatever the buffer holds and ends with flag bit 3 (later exchanges do not wait again).
+// the rows of exchange number `epoch` are stored: publish, wait for the team (see above for what a timeout does)
 __device__ __forceinline__ void team_sync(const Lds& v, int tid, unsigned epoch) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through stores have left
     __syncthreads();
@@ -816,335 +741,28 @@ __device__ __forceinline__ void team_sync(const Lds& v, int tid, unsigned epoch)
         gu32* flags = reinterpret_cast<gu32*>(team_ptr(v, TM_FLAGS));
         const int S = v.misc[TM_S], rank = v.misc[TM_RANK];
         const unsigned target = epoch + 1u;
-        if (tid == 0) __hip_atomic_store(flags + rank, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool ok = true;
-        if (v.misc[TM_FAIL] == 0) {
-            ok = false;
+        bool failed = v.misc[TM_FAIL] != 0;
+        if (tid == 0) __hip_atomic_store(flags + rank, failed ? TEAM_POISON : target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!failed) {
+            bool ok = false;
             for (unsigned spins = 0; spins < TEAM_SPIN_LIMIT; ++spins) {
                 unsigned f = target;
                 if (tid < S) f = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__any(f == TEAM_POISON)) break;            // somebody gave up: so do we
                 if (__all(int(f - target) >= 0)) { ok = true; break; }
                 __builtin_amdgcn_s_sleep(2);
+            }
+            if (!ok) {
+                failed = true;
+                if (tid == 0) __hip_atomic_store(flags + rank, TEAM_POISON, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (tid == 0) {
             v.misc[TM_EPOCH] = int(target);
-            if (!ok) v.misc[TM_FAIL] = 1;
+            if (failed) v.misc[TM_FAIL] = 1;
         }
     }
     __syncthreads();
-}
-
-// GCL: sums of the slot partials of the own receivers (chunks ascending) -> exchange -> every aggregate row in v.C; max |agg|
-__device__ __forceinline__ float team_exchange_gcl(const Lds& v, int nb, int tid, float scale) {
-    const int r0 = v.misc[TM_R0], nrec = v.misc[TM_NREC];
-    const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
-    const SlotPlan pl = slot_plan(nrec, nb);
-    const __amdgpu_buffer_rsrc_t rows = team_rows(v);
-    const int pbase = int(epoch & 1u) * TEAM_ROW_BYTES;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int e = tid + THREADS * k;
-        if (e < nrec * 32) {
-            const float* src = v.A + (e >> 5) * pl.g * PB_STRIDE + 4 * (e & 31);
-            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int ch = 0; ch < pl.g; ++ch) {
-                const float4 p = *reinterpret_cast<const float4*>(src + ch * PB_STRIDE);
-                s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-            }
-            const u32x4 bits = {__float_as_uint(s.x * scale), __float_as_uint(s.y * scale), __float_as_uint(s.z * scale),
-                                __float_as_uint(s.w * scale)};
-            __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + ((r0 + (e >> 5)) * HID + 4 * (e & 31)) * 4, 0, 16);  // aux 16: sc1
-        }
-    }
-    team_sync(v, tid, epoch);              // (its first barrier also ends every read of the partial rows: P, Q, H, W2' are free)
-    float am = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int e = tid + THREADS * k;
-        if (e < nb * 32) {
-            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + ((e >> 5) * HID + 4 * (e & 31)) * 4, 0, 16);
-            const float4 a = make_float4(__uint_as_float(bits.x), __uint_as_float(bits.y), __uint_as_float(bits.z), __uint_as_float(bits.w));
-            *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = a;
-            am = fmaxf(fmaxf(am, fmaxf(fabsf(a.x), fabsf(a.y))), fmaxf(fabsf(a.z), fabsf(a.w)));
-        }
-    }
-    return am;
-}
-// coordinate head: the triples of the own receivers -> exchange -> v.aggx of every atom
-__device__ __forceinline__ void team_exchange_equiv(const Lds& v, int nb, int tid, float scale) {
-    const int nr = v.misc[MS_NRCV], S = v.misc[TM_S], rank = v.misc[TM_RANK];
-    const int r0 = (nr * rank) / S, nrec = (nr * (rank + 1)) / S - r0;       // this member's share of the receiver list
-    const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
-    const SlotPlan pl = slot_plan(nrec, nb);
-    const __amdgpu_buffer_rsrc_t rows = team_rows(v);
-    const int pbase = int(epoch & 1u) * TEAM_ROW_BYTES;
-    const int k = tid < nb ? v.rpos[tid] : -1;                               // thread = atom; rows are indexed by atom
-    if (k >= r0 && k < r0 + nrec) {
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int ch = 0; ch < pl.g; ++ch) {
-            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * ((k - r0) * pl.g + ch));
-            sx += p.x; sy += p.y; sz += p.z;
-        }
-        const u32x4 bits = {__float_as_uint(sx * scale), __float_as_uint(sy * scale), __float_as_uint(sz * scale), 0u};
-        __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + tid * HID * 4, 0, 16);
-    }
-    team_sync(v, tid, epoch);
-    if (k >= 0) {
-        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + tid * HID * 4, 0, 16);
-        v.aggx[4 * tid + 0] = __uint_as_float(bits.x); v.aggx[4 * tid + 1] = __uint_as_float(bits.y);
-        v.aggx[4 * tid + 2] = __uint_as_float(bits.z);
-    }
-}
-
-// scale of the edge-pass A-fragments: |u| <= |y| <= |P|+|Q| + r*|wr'| + d0*|wd'|,  r <= 4 max|x|^2
-__device__ __forceinline__ float edge_a_scale(const Lds& v, const float* __restrict__ sc) {
-    const float pq = __uint_as_float(v.fmax[FM_PQ]);
-    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
-    return scale_for(2.0f * pq + 4.0f * (x2 * sc[6] + x02 * sc[7]));
-}
-
-// The node features h have to outlive a GCL pair loop (node MLP input and residual), and the loop overwrites every LDS
-// region that could hold them.  They used to ride through it as a 32x32 register tile per wave - i.e. through scratch, the
-// loop takes every VGPR - and be written back to LDS afterwards (3.3 us per pass on the critical path).  Now the node MLP
-// also writes its new h rows to a per-workgroup HBM buffer `hs` [n][128] (L2-resident), and after the loop the rows come
-// back into v.A by LDS-DMA (global_load_lds, 256 B per wave instruction, no registers), issued as soon as the slot partials
-// have been read and BEFORE the next W2' image, so that waiting for them (vmcnt) does not wait for the image.
-__device__ __forceinline__ void hsave_dma(const Lds& v, const float* __restrict__ hs, int nb, int w, int lane) {
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    for (int r = w; r < nb; r += GWAVES) {
-        const float* src = hs + r * HID + lane;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(v.A + r * LDH), 4, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + 64), (lptr_t)(v.A + r * LDH + 64), 4, 0, 0);
-    }
-}
-// the h rows have landed; the W2' image (8 DMA instructions per wave, 9 in the two waves that also fetch the vectors)
-// issued after them may still be in flight
-__device__ __forceinline__ void hsave_wait(bool image_follows, int w) {
-    if (!image_follows) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (w < 4 * HID / 256) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-}
-
-// GCL (egnn.py:45-80) on the LDS-resident molecule; `hs`: this workgroup's h rows in HBM (see above).
-// `par` (f16x3): which of the two h-magnitude slots is current; toggled when h is rewritten.
-template <int PREC, bool TEAM>
-__device__ __forceinline__ void gcl_pass(const Lds& v, int nb, const float* __restrict__ g,
-                                         float* __restrict__ hs, const int8_t* __restrict__ emask, int N, Prof& pf, int& par,
-                                         PreW& pw, const NextPass nx, const ModelDims& md) {
-    const float* vecs = g + G_VEC;
-    const float* sc = g + G_SCALE;
-    float s_h;
-    {   // ---- front: projections + pair loop
-    const LaneIds q = lane_ids();
-    const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, nt = q.nt;
-    prof_event(pf, w, lane, 10);
-    if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; v.fmax[FM_T] = 0u; }
-    s_h = (PREC == 1) ? scale_for(__uint_as_float(__builtin_amdgcn_readfirstlane(v.fmax[FM_H0 + par]))) : 1.0f;
-    {
-        // first-layer projections P,Q (fragments prefetched: `pw`; the W2' image is arriving by DMA)
-        const float S1 = (PREC == 1 && w >= 4) ? geo_scale(v, sc) : 1.0f;        // sender rows: times S1 (see geo_scale)
-        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) * S1 : 1.0f;
-        const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
-        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax * inv_pow2(S1), lane);
-    }
-    prof_event(pf, w, lane, 11);
-    dma_wait();
-    lds_barrier();                         // P, Q, W2', vectors in place; every read of H (v.C) done
-    prof_event(pf, w, lane, 12);
-    float sa = 1.0f, accs = 1.0f;
-    if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[5]; }
-    // ends with the partial rows in LDS
-    if (md.attention) pair_phase<false, PREC, true, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, sc[8], pf);
-    else pair_phase<false, PREC, false, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
-    prof_event(pf, w, lane, 13);
-    }
-    // ---- back: aggregate completion + node MLP (lane indices re-derived, see lane_ids)
-    const LaneIds q = lane_ids();
-    const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
-    const bool active = (mt == 0) || (nb > 32);
-#ifdef DL_V_EARLY
-    // the node MLP's first-layer fragments (32 KB per wave from L2) are requested HERE, a reduction and two barriers before
-    // their use, and AHEAD of the h rows and of the next W2' image in the memory pipeline (loads return in order)
-    BFrag b3a, b3b;
-    if (active) {
-        b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
-        b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
-    }
-#endif
-    lds_barrier();                         // partial rows complete
-    prof_event(pf, w, lane, 20);
-    if constexpr (TEAM) {
-        const float am = team_exchange_gcl(v, nb, tid, md.mean ? 1.0f / float(N) : 1.0f);    // every aggregate row -> v.C
-        hsave_dma(v, hs, nb, w, lane);     // h rows -> v.A
-#ifndef DL_V_EARLY
-        stage_next(v, nx, w, tid);
-#endif
-        if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
-        if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
-    } else {
-        AggRegs ar;
-        const float am = pair_reduce_gcl(v, nb, tid, ar, md.mean ? 1.0f / float(N) : 1.0f);
-        prof_event(pf, w, lane, 21);
-        lds_barrier();                     // every partial read: P, Q, H, W2' regions are free
-        prof_event(pf, w, lane, 22);
-        hsave_dma(v, hs, nb, w, lane);     // h rows -> v.A
-#ifndef DL_V_EARLY
-        stage_next(v, nx, w, tid);         // next pass's W2' image: DMA under the node phases
-#endif
-        if (PREC == 1 && tid == 0) v.fmax[FM_PQ] = 0u;
-        pair_store_gcl(v, nb, tid, ar);    // aggregate -> v.C
-        if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
-    }
-    prof_event(pf, w, lane, 23);
-#ifdef DL_V_EARLY
-    hsave_wait(false, w);
-#else
-    hsave_wait(nx.base != nullptr, w);
-#endif
-    prof_event(pf, w, lane, 25);
-    lds_barrier();
-    prof_event(pf, w, lane, 14);
-    // node MLP layer 1 over [h | agg]  (K = 256), u-form SiLU -> v.B
-    BFrag b4f;
-    floatx16 acc1;
-    float s2 = 1.0f, inv1 = 1.0f;
-    if (active) {
-#ifndef DL_V_EARLY
-        // fragments requested at the point of use
-        BFrag b3a = load_bfrag(g + G_W3A + nt * (UNIT / 4), lane);
-        BFrag b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
-#endif
-        const float b3 = vecs[4 * HID + 32 * nt + c];
-        float s1 = 1.0f;
-        if (PREC == 1) {
-            // one accumulator for both K-blocks: common total scale S = sa_i * sw_i
-            const float S = fminf(s_h * sc[2], scale_for(__uint_as_float(v.fmax[FM_AGG])) * sc[3]);
-            s1 = S * inv_pow2(sc[2]); s2 = S * inv_pow2(sc[3]); inv1 = inv_pow2(S);
-        }
-        acc1 = splat16(PREC == 0 ? b3 : 0.0f);
-        const int arow = min(32 * mt + c, nb - 1);
-        gemm_k128<PREC>(acc1, v.A, arow, hh, b3a, s1);
-        b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);         // for layer 2, under layer 1's second GEMM
-#ifdef DL_V_EARLY
-    }
-    prof_event(pf, w, lane, 104);
-    stage_next(v, nx, w, tid);             // next pass's W2' image (64 KB by LDS-DMA), behind every fragment this pass still needs
-    if (active) {
-        const float b3 = vecs[4 * HID + 32 * nt + c];
-        const int arow = min(32 * mt + c, nb - 1);
-#endif
-        floatx16& acc = acc1;
-        const float inv = inv1;
-        gemm_k128<PREC>(acc, v.C, arow, hh, b3b, s2);
-        prof_event(pf, w, lane, 105);
-        float tmax = 0.0f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 32 * mt + acc_row(reg, hh);
-            const float tval = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, b3));
-            store_row(v, v.B, row, nb, 32 * nt + c, tval);
-            tmax = fmaxf(tmax, row < nb ? fabsf(tval) : 0.0f);
-        }
-        if (PREC == 1) block_max(&v.fmax[FM_T], tmax, lane);
-    }
-    prof_event(pf, w, lane, 15);
-    lds_barrier();
-    // node MLP layer 2 + residual; new h -> registers and v.C (row-major, for the next projections)
-    load_next(pw, nx, w, lane);            // the next pass's projection fragments, under layer 2
-    if (active) {
-        const float b4 = vecs[5 * HID + 32 * nt + c];
-        float s_t = 1.0f, inv = 1.0f;
-        if (PREC == 1) { s_t = scale_for(__uint_as_float(v.fmax[FM_T])); inv = inv_pow2(s_t * sc[4]); }
-        // residual: the old h is still in v.A (rows >= n_b: whatever row min(row, n_b-1) holds; those results go to the sink)
-        floatx16 hold;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) hold[reg] = v.A[min(32 * mt + acc_row(reg, hh), nb - 1) * LDH + 32 * nt + c];
-        floatx16 acc;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) acc[reg] = (PREC == 0) ? hold[reg] + b4 : 0.0f;
-        const int arow = min(32 * mt + c, nb - 1);
-        prof_event(pf, w, lane, 106);
-        gemm_k128<PREC>(acc, v.B, arow, hh, b4f, s_t);
-        prof_event(pf, w, lane, 107);
-        float hmax = 0.0f;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = 32 * mt + acc_row(reg, hh);
-            const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hold[reg] + b4);
-            store_row(v, v.C, row, nb, 32 * nt + c, hv);
-            if (row < nb) hs[row * HID + 32 * nt + c] = hv;
-            hmax = fmaxf(hmax, row < nb ? fabsf(hv) : 0.0f);
-        }
-        if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hmax, lane);
-    }
-    par ^= 1;
-    prof_event(pf, w, lane, 16);
-    lds_barrier();
-}
-
-// EquivariantUpdate (egnn.py:101-125): x_i += (sum_j cdiff_ij * s_ij * m_ij / norm) * linker_mask_i
-template <int PREC, bool TEAM>
-__device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __restrict__ e,
-                                           const int8_t* __restrict__ emask, int N, float norm_constant, Prof& pf,
-                                           int par, PreW& pw, const NextPass nx, const ModelDims& md) {
-    const float* vecs = e + E_VEC;
-    const float* sc = e + E_SCALE;
-    {   // ---- front: projections + pair loop
-    const LaneIds q = lane_ids();
-    const int w = q.w, lane = q.lane, c = q.c, nt = q.nt;
-    prof_event(pf, w, lane, 30);
-    {
-        const float s_h = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0 + par])) : 1.0f;
-        const float S1 = (PREC == 1 && w >= 4) ? geo_scale(v, sc) : 1.0f;
-        const float inv = (PREC == 1) ? inv_pow2(s_h * sc[w < 4 ? 0 : 1]) * S1 : 1.0f;
-        const float vmax = node_pre<PREC>(v, nb, w, lane, pw.bf, (w < 4) ? vecs[32 * nt + c] : 0.0f, s_h, inv);
-        if (PREC == 1) block_max(&v.fmax[FM_PQ], vmax * inv_pow2(S1), lane);
-    }
-    prof_event(pf, w, lane, 31);
-    dma_wait();
-    lds_barrier();
-    prof_event(pf, w, lane, 32);
-    float sa = 1.0f, accs = 1.0f;
-    if (PREC == 1) { sa = edge_a_scale(v, sc); accs = sa * sc[2]; }
-    pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
-                                  md.tanh ? md.coords_range : 0.0f, pf);      // ends with the partial triples in LDS
-    prof_event(pf, w, lane, 33);
-    }
-    // ---- back: coordinate update (lane indices re-derived, see lane_ids)
-    const LaneIds q = lane_ids();
-    const int tid = q.tid, w = q.w, lane = q.lane;
-    load_next(pw, nx, w, lane);            // next block's first pass, under the reduction
-    lds_barrier();                         // partial triples complete
-    // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
-    const float xscale = md.mean ? 1.0f / float(N) : (md.tanh ? md.inv_norm : 1.0f);
-    if constexpr (TEAM) {
-        team_exchange_equiv(v, nb, tid, xscale);             // (barriers inside: partials read, P, Q, W2' regions are free)
-    } else {
-        pair_reduce_equiv(v, nb, tid, xscale);
-        lds_barrier();                     // partials read: P, Q, W2' regions are free
-    }
-    stage_next(v, nx, w, tid);
-    if (PREC == 1 && tid == 0) { v.fmax[FM_PQ] = 0u; v.fmax[FM_X2] = 0u; }
-    lds_barrier();
-    float n2 = 0.0f;
-    if (tid < nb) {
-        const float lm = v.lm[tid];
-        const bool moves = v.rpos[tid] >= 0;                     // off the receiver list: linker mask 0, nothing was summed
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float xn = v.xs[4 * tid + k];
-            if (moves) {
-                xn += v.aggx[4 * tid + k] * lm;
-                v.xs[4 * tid + k] = xn;
-            }
-            n2 = fmaf(xn, xn, n2);
-        }
-    }
-    if (PREC == 1) block_max(&v.fmax[FM_X2], n2, lane);
-    prof_event(pf, w, lane, 34);
-    lds_barrier();
 }
 
 // ===================================================================================================
@@ -1165,7 +783,7 @@ __device__ __forceinline__ void equiv_pass(const Lds& v, int nb, const float* __
 //   * weight fragments, T0 and the residual rows are requested a phase ahead, always in the order they are needed
 //     (vector-memory returns in order: a prefetch issued BEFORE a load delays that load), biases ride in T0 / the residual.
 // Per-workgroup HBM scratch `hs` (floats): h rows fp32 [NMAX][HID] (residual, output head), then T0 tiles [8][16][64].
-constexpr int HS_H = 0;
+constexpr int HS_HF = 0;                      // (teams, molecules of more than 55 atoms) the h fragment rows across a coordinate pass
 constexpr int HS_T0 = NMAX * HID;
 constexpr int HS_HT = HS_T0 + 8 * 16 * 64;    // the h rows once more, as tiles in accumulator order (the residual of the node MLP)
 constexpr int HS_STRIDE = HS_HT + 8 * 16 * 64;
@@ -1187,7 +805,7 @@ constexpr int SCE_L1_W5A = 8, SCE_L1_W5B = 9, SCE_B5 = 10;
 // reload afterwards waits for ALL vector-memory traffic in flight (s_waitcnt vmcnt(0): the counter is in order) - measured
 // round 3: ten such reloads in the 2 us reduction alone.
 constexpr int CX_N = 16, CX_EM = 17, CX_HS = 19, CX_WP = 21, CX_PASS = 23, CX_PAR = 24, CX_FLAGS = 25, CX_NORMC = 26,
-              CX_CRANGE = 27, CX_INVNORM = 28, CX_NPASS = 29, CX_NF = 30, CX_FIN = 31, CX_TFEAT = 32, CX_MOL = 33;
+              CX_CRANGE = 27, CX_INVNORM = 28, CX_NPASS = 29, CX_NF = 30, CX_FIN = 31, CX_TFEAT = 32, CX_MOL = 33, CX_CTXP = 34;
 __device__ __forceinline__ int ctx_i(const Lds& v, int k) {
     typedef volatile __attribute__((address_space(3))) int* lds_vint_t;       // a plain ds_read_b32 (a volatile GENERIC access is a flat sc0 sc1 load)
     return __builtin_amdgcn_readfirstlane(*(lds_vint_t)(v.misc + k));
@@ -1316,10 +934,11 @@ __device__ __forceinline__ void load_pre2(PreW2& pw, const NextPass& nx, int w, 
     load_pre2_u1(pw, nx, w, lane);
 }
 
-// P (waves 0-3) / Q (waves 4-7) of both atom tiles and, in a GCL, T0 of atom tile (wave half), from the h fragment rows in v.C.
-// Returns the bound on |P| + |Q| the edge pass scales its first layer with.
-template <int PREC, bool GCLP>
-__device__ __forceinline__ void pre_phase(const Lds& v, int nb, int w, int lane, const PreW2& pw, const float* __restrict__ vecs,
+// P (waves 0-3) / Q (waves 4-7) of both atom tiles of the OWN atoms and, in a GCL, T0 of atom tile (wave half), from the h
+// fragment rows in v.C.  A team's Q rows are stored without the geometric scale S1 (the consumer applies its own, see
+// team_exchange_q); one workgroup per molecule stores them times S1 (see geo_scale).
+template <int PREC, bool GCLP, bool TEAM>
+__device__ __forceinline__ void pre_phase(const Lds& v, int nown, int w, int lane, const PreW2& pw, const float* __restrict__ vecs,
                                           const float* __restrict__ sc, float* __restrict__ hs, float s_hf) {
     const int c = lane & 31, hh = lane >> 5, nt = w & 3, half = w >> 2;
     float* dst = half ? v.B : v.A;
@@ -1328,17 +947,17 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nb, int w, int lane,
     float inv = 1.0f, inv3 = 1.0f;
     if (PREC == 1) {
         float S1 = 1.0f;                                                   // sender rows: times S1 (see geo_scale)
-        if (half) {
+        if (half && !TEAM) {
             const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
             S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(sc, 6)), scale_for(4.0f * x02) * scale_for(cload(sc, 7)));
         }
         inv = inv_pow2(s_hf * cload(sc, half)) * S1;
         if (GCLP) inv3 = inv_pow2(s_hf * cload(sc, 2));
     }
-    const int mtiles = nb > 32 ? 2 : 1;
+    const int mtiles = nown > 32 ? 2 : 1;
     AReg a;
     for (int mt = 0; mt < mtiles; ++mt) {
-        load_a<PREC>(a, v.C, min(32 * mt + c, nb - 1), hh);
+        load_a<PREC>(a, v.C, max(min(32 * mt + c, nown - 1), 0), hh);
         floatx16 acc = splat16(PREC == 0 ? bias : 0.0f);
         tile_mma<PREC>(acc, a, pw.u0);
         const bool t0 = GCLP && half == mt;
@@ -1350,7 +969,7 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nb, int w, int lane,
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
-            store_row(v, dst, row, nb, 32 * nt + c, (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias));
+            store_row(v, dst, row, nown, 32 * nt + c, (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias));
         }
         if (t0) {
             float* tp = hs + HS_T0 + (4 * mt + nt) * (16 * 64) + lane;
@@ -1360,27 +979,91 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nb, int w, int lane,
     }
 }
 
-// the projections (and T0) the NEXT pass opens with, from the h fragment rows in v.C; ends with every LDS operand of that
-// pass's pair loop in place.  Fragments are requested and used inside this one straight-line region: nothing of them is
-// carried around the pass loop (128 registers that the pair loop's 256 would push to scratch).
+// Team: the sender rows of the own atoms (v.B rows 0 .. n_own-1, as pre_phase left them) and their coordinates -> exchange ->
+// the sender row of EVERY atom in v.B (row = atom; through v.C when the molecule has more than 55), times the geometric
+// scale S1 of the pass being opened (`sc`: its scale block), the coordinates of every atom in v.xs (and in v.x0 at the first
+// exchange of a forward), max |x|^2 over the molecule in the OTHER bound slot (which becomes the current one), max |h| over
+// the molecule in FM_HG.  Ends with every LDS write done but NOT yet fenced by a barrier (the caller's follows).
 template <int PREC>
-__device__ __forceinline__ void open_pass(const Lds& v, int nb, const NextPass nx, float* __restrict__ hs, Prof& pf, const PreW2& pw,
-                                          int next_pass) {
+__device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, const float* __restrict__ sc, bool first, int par) {
+    const int S = v.misc[TM_S], rank = v.misc[TM_RANK], nown = v.misc[TM_NOWN];
+    const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
+    const int cur = v.misc[TM_XSLOT], nxt = cur ^ (FM_X2 ^ FM_X2B);
+    const __amdgpu_buffer_rsrc_t rows = team_rows(v);
+    const int pbase = int(epoch & 1u) * (NQMAX * TX_ROW * 4);
+    const int hbase = TEAM_X_BYTES + int(epoch & 1u) * (TEAM_MAX * 16);
+    for (int e = tid; e < nown * 33; e += THREADS) {           // 32 x 16 bytes of Q and 16 bytes of coordinates per own atom
+        const int l = e / 33, q4 = e - l * 33, a = rank + l * S;
+        const float4 val = (q4 < 32) ? *reinterpret_cast<const float4*>(v.B + l * LDH + 4 * q4)
+                                     : *reinterpret_cast<const float4*>(v.xs + 4 * a);
+        const u32x4 bits = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + (a * TX_ROW + 4 * q4) * 4, 0, 16);     // aux 16: sc1
+    }
+    if (tid == 0) {
+        const u32x4 hdr = {v.fmax[FM_H0 + par], 0u, 0u, 0u};
+        __builtin_amdgcn_raw_buffer_store_b128(hdr, rows, hbase + rank * 16, 0, 16);
+        v.fmax[nxt] = 0u; v.fmax[FM_HG] = 0u;
+    }
+    team_sync(v, tid, epoch);              // (its first barrier also ends every read of the own rows in v.B)
+    // coordinates first: S1 needs the new bound
+    float n2 = 0.0f;
+    if (tid < nb) {
+        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + (tid * TX_ROW + HID) * 4, 0, 16);
+        const float4 x = make_float4(__uint_as_float(bits.x), __uint_as_float(bits.y), __uint_as_float(bits.z), 0.0f);
+        *reinterpret_cast<float4*>(v.xs + 4 * tid) = x;
+        if (first) *reinterpret_cast<float4*>(v.x0 + 4 * tid) = x;
+        n2 = x.x * x.x + x.y * x.y + x.z * x.z;
+    }
+    if (tid < 128) {                                           // waves 0, 1: the atoms; one lane per member: its max |h|
+        unsigned hm = 0u;
+        if (tid < S) { const u32x4 hdr = __builtin_amdgcn_raw_buffer_load_b128(rows, hbase + tid * 16, 0, 16); hm = hdr.x; }
+        const unsigned b = wave_max_u32(__float_as_uint(n2)), hb = wave_max_u32(hm);
+        if ((tid & 63) == 0) {
+            atomicMax(&v.fmax[nxt], b);
+            if (first) atomicMax(&v.fmax[FM_X02], b);
+            if (tid == 0) atomicMax(&v.fmax[FM_HG], hb);
+        }
+    }
+    lds_barrier();
+    if (tid == 0) v.misc[TM_XSLOT] = nxt;                      // readers: after the caller's barrier
+    float S1 = 1.0f;
+    if (PREC == 1) {
+        const float x2 = __uint_as_float(v.fmax[nxt]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(sc, 6)), scale_for(4.0f * x02) * scale_for(cload(sc, 7)));
+    }
+    for (int e = tid; e < nb * 32; e += THREADS) {
+        const int a = e >> 5, q4 = e & 31;
+        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + (a * TX_ROW + 4 * q4) * 4, 0, 16);
+        *reinterpret_cast<float4*>(v.B + a * LDH + 4 * q4) =
+            make_float4(__uint_as_float(bits.x) * S1, __uint_as_float(bits.y) * S1, __uint_as_float(bits.z) * S1, __uint_as_float(bits.w) * S1);
+    }
+}
+
+// the projections (and T0) the NEXT pass opens with, from the h fragment rows in v.C; ends with every LDS operand of that
+// pass's pair loop in place.  Fragments are requested and used inside one straight-line region: nothing of them is
+// carried around the pass loop (128 registers that the pair loop's 256 would push to scratch).
+template <int PREC, bool TEAM>
+__device__ __forceinline__ void open_pass(const Lds& v, int nb, int nown, const NextPass nx, float* __restrict__ hs, Prof& pf,
+                                          const PreW2& pw, int next_pass, int par) {
     if (nx.base == nullptr) return;
     const LaneIds q = lane_ids();
     const int w = q.w, lane = q.lane;
     const float s_hf = (PREC == 1) ? __uint_as_float(v.fmax[FS_HS]) : 1.0f;
-    if (nx.equiv) pre_phase<PREC, false>(v, nb, w, lane, pw, nx.base + E_VEC, nx.base + E_SCALE, nullptr, s_hf);
-    else pre_phase<PREC, true>(v, nb, w, lane, pw, nx.base + G_VEC, nx.base + G_SCALE, hs, s_hf);
+    const float* sc = nx.base + (nx.equiv ? E_SCALE : G_SCALE);
+    if (nx.equiv) pre_phase<PREC, false, TEAM>(v, nown, w, lane, pw, nx.base + E_VEC, sc, nullptr, s_hf);
+    else pre_phase<PREC, true, TEAM>(v, nown, w, lane, pw, nx.base + G_VEC, sc, hs, s_hf);
+    if constexpr (TEAM) {
+        lds_barrier();                     // own Q rows complete
+        team_exchange_q<PREC>(v, nb, q.tid, sc, next_pass == 0, par);
+    }
     if (q.tid == 0) v.misc[CX_PASS] = next_pass;
     prof_event(pf, w, lane, 11);
     dma_wait();
-    lds_barrier();                         // P, Q, W2', vectors in place; every read of the h rows (v.C) done
+    lds_barrier();                         // P, Q, W2', vectors, coordinates in place; every read of the h rows (v.C) done
 }
 
-// GCL (egnn.py:45-80), per-atom phases version 2; P, Q, T0 of this pass are in place (open_pass).  `par`: which of the two
-// max|h| slots is current.  Ends with the next pass opened.
-template <int PREC>
+// GCL (egnn.py:45-80), per-atom phases version 2; P, Q, T0 of this pass are in place (open_pass).  Ends with the next pass opened.
+template <int PREC, bool TEAM>
 __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     {   // ---- pair loop
     const PassCtx cx = pass_ctx(v);
@@ -1393,19 +1076,20 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) {
-        const float hmax = __uint_as_float(v.fmax[FM_H0 + par]);
-        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);     // senders: any atom of the molecule
+        const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);            // >= |P_i| + |Q_j|
         sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
         accs = sa * cload(sc, 5);
     }
-    if (cx.flags & 1) pair_phase<false, PREC, true, false>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, cload(sc, 8), pf);
-    else pair_phase<false, PREC, false, false>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
+    if (cx.flags & 1) pair_phase<false, PREC, true, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, cload(sc, 8), pf);
+    else pair_phase<false, PREC, false, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
     prof_event(pf, w, lane, 13);
     }
-    // ---- aggregate, node MLP (context and lane indices re-derived: nothing lives across the loop)
+    // ---- aggregate, node MLP of the own atoms (context and lane indices re-derived: nothing lives across the loop)
     const PassCtx cx = pass_ctx(v);
     const int nb = cx.nb, N = cx.N, par = cx.par;
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
     const float* g = cx.g;
     float* hs = cx.hs;
     const NextPass nx = cx.nx;
@@ -1414,7 +1098,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     const bool mean = (cx.flags & 4) != 0;
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
-    const bool active = (mt == 0) || (nb > 32);
+    const bool active = (mt == 0) || (nown > 32);
     // layer 1's fragments and T0, AHEAD of the next W2' image in the memory pipeline
     BFrag b3b, b4f;
     float t0r[16], hold[16];
@@ -1429,7 +1113,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     lds_barrier();                         // partial rows complete
     prof_event(pf, w, lane, 20);
     AggRegs ar;
-    const float am = pair_reduce_gcl(v, nb, tid, ar, mean ? 1.0f / float(N) : 1.0f);
+    const float am = pair_reduce_gcl(v, nown, nb, tid, ar, mean ? 1.0f / float(N) : 1.0f);
     if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
     prof_event(pf, w, lane, 21);
     lds_barrier();                         // every partial read: P, Q, H, W2' regions are free; max |agg| known
@@ -1443,7 +1127,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {          // aggregate -> fragment rows in v.C
         const int e = tid + THREADS * k;
-        if (e < nb * 32) put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), ar.v[k], s_agg);
+        if (e < nown * 32) put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), ar.v[k], s_agg);
     }
     // bounds: |y3| <= L1(W3a') max|h| + L1(W3b') max|agg| + max|b3'|  >= |t| ;  |h_new| <= max|h| + L1(W4') |t| + max|b4|
     const float y3b = cload(sc, SC_L1_W3A) * hmax + cload(sc, SC_L1_W3B) * aggmax + cload(sc, SC_B3);
@@ -1454,11 +1138,11 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     lds_barrier();
     prof_event(pf, w, lane, 14);
     // node MLP layer 1: t = SiLU(T0 + W3b' agg)  -> fragment rows in v.B
-    const int arow = min(32 * mt + c, nb - 1);
+    const int arow = max(min(32 * mt + c, nown - 1), 0);
     if (active) {
         AReg a;
         load_a<PREC>(a, v.C, arow, hh);
-        // for layer 2, under layer 1: its fragments, the residual rows (written by this lane, a pass ago), the bias
+        // for layer 2, under layer 1: its fragments, the residual tile (written by this lane, a pass ago), the bias
         b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
         const float* hp = hs + HS_HT + (4 * mt + nt) * (16 * 64) + lane;
 #pragma unroll
@@ -1475,7 +1159,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float tval = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, t0r[reg]));
-            put_elem<PREC>(row < nb ? v.B + row * LDH : v.dummy, 32 * nt + c, tval, s_t);
+            put_elem<PREC>(row < nown ? v.B + row * LDH : v.dummy, 32 * nt + c, tval, s_t);
         }
     }
     prof_event(pf, w, lane, 15);
@@ -1506,9 +1190,9 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hold[reg] + b4);
-            put_elem<PREC>(row < nb ? v.C + row * LDH : v.dummy, 32 * nt + c, hv, s_hn);
+            put_elem<PREC>(row < nown ? v.C + row * LDH : v.dummy, 32 * nt + c, hv, s_hn);
             hs[HS_HT + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hv;
-            hm = fmaxf(hm, row < nb ? fabsf(hv) : 0.0f);
+            hm = fmaxf(hm, row < nown ? fabsf(hv) : 0.0f);
         }
         if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
     }
@@ -1518,13 +1202,20 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     }
     prof_event(pf, w, lane, 16);
     lds_barrier();
+    if constexpr (TEAM) {
+        // a molecule of more than 55 atoms: the sender rows of the coming coordinate pass reach into v.C - the h fragment rows
+        // go to the HBM scratch and come back after that pair loop (equiv_pass2)
+        if (nx.equiv && nb > NMAX)
+            for (int e = tid; e < nown * 32; e += THREADS)
+                *reinterpret_cast<float4*>(hs + HS_HF + (e >> 5) * HID + 4 * (e & 31)) = *reinterpret_cast<const float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31));
+    }
     prof_event(pf, w, lane, 10);
-    open_pass<PREC>(v, nb, nx, hs, pf, pw, cx.pass + 1);
+    open_pass<PREC, TEAM>(v, nb, nown, nx, hs, pf, pw, cx.pass + 1, par ^ 1);
 }
 
 // EquivariantUpdate (egnn.py:101-125), per-atom phases version 2: the h fragment rows in v.C survive the pass; P, Q of
 // this pass are in place (open_pass); ends with the next pass opened.
-template <int PREC>
+template <int PREC, bool TEAM>
 __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     {   // ---- pair loop
     const PassCtx cx = pass_ctx(v);
@@ -1537,19 +1228,21 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) {
-        const float hmax = __uint_as_float(v.fmax[FM_H0 + par]);
-        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
+        const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
         sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
         accs = sa * cload(sc, 2);
     }
-    pair_phase<true, PREC, false, false>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
-                                         (cx.flags & 2) ? ctx_f(v, CX_CRANGE) : 0.0f, pf);      // ends with the partial triples in LDS
+    pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
+                                        (cx.flags & 2) ? ctx_f(v, CX_CRANGE) : 0.0f, pf);      // ends with the partial triples in LDS
     prof_event(pf, w, lane, 33);
     }
-    // ---- coordinate update (context and lane indices re-derived: nothing lives across the loop)
+    // ---- coordinate update of the own atoms (context and lane indices re-derived: nothing lives across the loop)
     const PassCtx cx = pass_ctx(v);
     const int nb = cx.nb, N = cx.N;
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+    const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
     float* hs = cx.hs;
     const NextPass nx = cx.nx;
     const LaneIds q = lane_ids();
@@ -1560,49 +1253,59 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     lds_barrier();                         // partial triples complete
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
     const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
-    pair_reduce_equiv(v, nb, tid, xscale);
+    pair_reduce_equiv(v, nown, nb, tid, xscale);
     lds_barrier();                         // partials read: P, Q, W2' regions are free
     stage_next(v, nx, w, tid);
-    if (PREC == 1 && tid == 0) v.fmax[FM_X2] = 0u;
-    lds_barrier();
+    if constexpr (TEAM) {
+        if (nb > NMAX && nx.base != nullptr)                           // the h fragment rows back into v.C (see gcl_pass2)
+            for (int e = tid; e < nown * 32; e += THREADS)
+                *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = *reinterpret_cast<const float4*>(hs + HS_HF + (e >> 5) * HID + 4 * (e & 31));
+    } else {
+        if (PREC == 1 && tid == 0) v.fmax[FM_X2] = 0u;
+        lds_barrier();
+    }
     float n2 = 0.0f;
-    if (tid < nb) {
+    if (tid < nown) {
         const float lm = v.lm[tid];
+        const int a = rank + tid * S;
         const bool moves = v.rpos[tid] >= 0;                     // off the receiver list: linker mask 0, nothing was summed
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            float xn = v.xs[4 * tid + k];
+            float xn = v.xs[4 * a + k];
             if (moves) {
                 xn += v.aggx[4 * tid + k] * lm;
-                v.xs[4 * tid + k] = xn;
+                v.xs[4 * a + k] = xn;
             }
             n2 = fmaf(xn, xn, n2);
         }
     }
-    if (PREC == 1) block_max(&v.fmax[FM_X2], n2, lane);
+    if (PREC == 1 && !TEAM) block_max(&v.fmax[FM_X2], n2, lane);       // (a team: from the next exchange, over every atom)
     prof_event(pf, w, lane, 34);
     lds_barrier();
     prof_event(pf, w, lane, 10);
-    open_pass<PREC>(v, nb, nx, hs, pf, pw, cx.pass + 1);
+    open_pass<PREC, TEAM>(v, nb, nown, nx, hs, pf, pw, cx.pass + 1, cx.par);
 }
 
+template <bool TEAM>
 __device__ __forceinline__ void head_phase(const Lds& v);
 
-// Dynamics.forward for the molecule resident in LDS, per-atom phases version 2 (see forward_molecule for the contract)
-// The context words (CX_*: sizes, pointers, model flags, time feature) are set by the kernel; CX_PASS / CX_PAR are reset here.
-template <int PREC>
+// Dynamics.forward for the own atoms of the molecule resident in LDS: reads v.z (state), the linker mask v.lm, the context
+// words (CX_*: sizes, pointers, model flags, time feature; set by the kernel - CX_PASS / CX_PAR are reset here);
+// writes eps_hat[l][0:3+nf] of own atom l into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
+template <int PREC, bool TEAM>
 __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int tid = lane_ids().tid;
     const int nb = ctx_i(v, 0);
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+    const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
     const float* wp = ctx_p<const float>(v, CX_WP);
     float* hs = ctx_p<float>(v, CX_HS);
     const float tfeat = ctx_f(v, CX_TFEAT);
-    ModelDims md;
-    md.nf = ctx_i(v, CX_NF); md.fin = ctx_i(v, CX_FIN);
+    const int nf = ctx_i(v, CX_NF), fin = ctx_i(v, CX_FIN);
     const int npass = ctx_i(v, CX_NPASS);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
+    if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; if (TEAM) v.misc[TM_XSLOT] = FM_X2; }
     prof_event(pf, w, lane, 1);
     if (PREC == 1) {
         if (tid < 8) v.fmax[tid] = 0u;
@@ -1610,14 +1313,15 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     }
     const NextPass first = {wp + OFF_BLOCKS, false};
     stage_next(v, first, w, tid);                                   // first pass's W2' image (v.W, v.vec are free here)
-    // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
-    if (tid < 4 * nb) {
-        const int a = tid >> 2, k = tid & 3;
-        const float xv = (k < 3) ? v.z[a * DMAX + k] : 0.0f;
-        v.xs[tid] = xv;
-        v.x0[tid] = xv;
+    // coordinates at entry of the own atoms (x, and x0 for the d0 edge attribute and the velocity); a team gets everybody's
+    // from its first exchange
+    if (tid < 4 * nown) {
+        const int l = tid >> 2, k = tid & 3, a = rank + l * S;
+        const float xv = (k < 3) ? v.z[l * DMAX + k] : 0.0f;
+        v.xs[4 * a + k] = xv;
+        v.x0[4 * a + k] = xv;
     }
-    if (PREC == 1) {
+    if (PREC == 1 && !TEAM) {
         float n2 = 0.0f;
         if (tid < nb) {
             const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
@@ -1637,21 +1341,24 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
             wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
         }
         const float be = wp[OFF_EMB_B + f];
+        const float* ctxp = ctx_p<const float>(v, CX_CTXP);                 // this molecule's context rows [N][nctx]
+        const int nctx = fin - nf - 1;
         float hmax = 0.0f;
-        for (int a = tid >> 7; a < nb; a += THREADS / HID) {
+        for (int l = tid >> 7; l < nown; l += THREADS / HID) {
+            const int pos = v.idx[rank + l * S];
             float acc = be;
 #pragma unroll
             for (int k = 0; k < FINP; ++k) {
                 float hin = 0.0f;
-                if (k < md.nf) hin = v.z[a * DMAX + 3 + k];
-                else if (k == md.nf) hin = tfeat;
-                else if (k < md.fin) hin = v.ctx[a * CTXMAX + (k - md.nf - 1)];
+                if (k < nf) hin = v.z[l * DMAX + 3 + k];
+                else if (k == nf) hin = tfeat;
+                else if (k < fin) hin = ctxp[pos * nctx + (k - nf - 1)];
                 acc = fmaf(wrow[k], hin, acc);
             }
-            v.B[a * LDH + f] = acc;
-            {   // accumulator-order copy: row a of tile (a / 32, f / 32) sits in register (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1
-                const int r = a & 31;
-                hs[HS_HT + (((a >> 5) * 4 + (f >> 5)) * 16 + (r & 3) + 4 * (r >> 3)) * 64 + (f & 31) + 32 * ((r >> 2) & 1)] = acc;
+            v.B[l * LDH + f] = acc;
+            {   // accumulator-order copy: row l of tile (l / 32, f / 32) sits in register (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1
+                const int r = l & 31;
+                hs[HS_HT + (((l >> 5) * 4 + (f >> 5)) * 16 + (r & 3) + 4 * (r >> 3)) * 64 + (f & 31) + 32 * ((r >> 2) & 1)] = acc;
             }
             hmax = fmaxf(hmax, fabsf(acc));
         }
@@ -1660,7 +1367,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     __syncthreads();
     {   // fragment rows of the embedded h -> v.C
         const float s0 = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
-        for (int e = tid; e < nb * 32; e += THREADS)
+        for (int e = tid; e < nown * 32; e += THREADS)
             put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), *reinterpret_cast<const float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)), s0);
         if (PREC == 1 && tid == 0) v.fmax[FS_HS] = __float_as_uint(s0);
     }
@@ -1669,31 +1376,33 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     {
         PreW2 pw;
         load_pre2(pw, first, w, lane);
-        open_pass<PREC>(v, nb, first, hs, pf, pw, 0);
+        open_pass<PREC, TEAM>(v, nb, nown, first, hs, pf, pw, 0, 0);
     }
 #pragma nounroll
     for (int p = 0; p < npass; p += 3) {
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) gcl_pass2<PREC>(v, pf);
-        equiv_pass2<PREC>(v, pf);
+        for (int gi = 0; gi < 2; ++gi) gcl_pass2<PREC, TEAM>(v, pf);
+        equiv_pass2<PREC, TEAM>(v, pf);
     }
     prof_event(pf, w, lane, 3);
     __syncthreads();                                               // the h tiles in the HBM scratch: written by other lanes
-
     // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
-    head_phase(v);
+    head_phase<TEAM>(v);
     prof_event(pf, w, lane, 4);
 }
 
 // (its own context reads: the pass loop above must not keep these alive)
+template <bool TEAM>
 __device__ __forceinline__ void head_phase(const Lds& v) {
     const int tid = lane_ids().tid;
     const int nb = ctx_i(v, 0), nf = ctx_i(v, CX_NF);
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+    const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
     const float* wp = ctx_p<const float>(v, CX_WP);
     const float* hs = ctx_p<const float>(v, CX_HS);
     float* eps = v.A;
     int nanbits = 0;
-    for (int e = tid; e < nb * nf; e += THREADS) {
+    for (int e = tid; e < nown * nf; e += THREADS) {
         const int a = e / nf, o = e - a * nf;
         // row a of the accumulator-order tiles: 32 consecutive floats per feature tile (k ascending: the reference's order)
         const int r = a & 31;
@@ -1712,131 +1421,21 @@ __device__ __forceinline__ void head_phase(const Lds& v) {
         eps[a * DMAX + 3 + o] = acc;
         if (acc != acc) nanbits |= 2;
     }
-    if (tid < 4 * nb && (tid & 3) < 3) {
-        const float vel = v.xs[tid] - v.x0[tid];
-        eps[(tid >> 2) * DMAX + (tid & 3)] = vel;
+    if (tid < 4 * nown && (tid & 3) < 3) {
+        const int l = tid >> 2, a = rank + l * S;
+        const float vel = v.xs[4 * a + (tid & 3)] - v.x0[4 * a + (tid & 3)];
+        eps[l * DMAX + (tid & 3)] = vel;
         if (vel != vel) nanbits |= 1;
     }
+    if (TEAM && tid == 0 && v.misc[TM_FAIL] != 0) nanbits |= 8;       // the team never assembled: the result is void
     if (nanbits) atomicOr(&v.misc[1], nanbits);
     __syncthreads();
 }
 
-// Dynamics.forward for the molecule resident in LDS: reads v.z (state), v.ctx, v.lm, time feature t;
-// writes eps_hat[a][0:3+nf] into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
-template <int PREC, bool TEAM>
-__device__ __forceinline__ void forward_molecule(const Lds& v, int nb, int tid, const ModelDims& md,
-                                                 const float* __restrict__ wp, float tfeat,
-                                                 const int8_t* __restrict__ emask, int N, Prof& pf, float* __restrict__ hs) {
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lane = tid & 63;
-    const int c = lane & 31, hh = lane >> 5;
-    const int nt = w & 3, mt = w >> 2;
-    prof_event(pf, w, lane, 1);
-    if (PREC == 1) {
-        if (tid < 8) v.fmax[tid] = 0u;
-        __syncthreads();
-    }
-
-    PreW pw;
-    {                                                               // first pass's weights (v.W, v.vec are free here)
-        const NextPass first = {wp + OFF_BLOCKS, false};
-        stage_next(v, first, w, tid);
-        load_next(pw, first, w, lane);
-    }
-
-    // coordinates at entry (x, and x0 for the d0 edge attribute and the velocity)
-    if (tid < 4 * nb) {
-        const int a = tid >> 2, k = tid & 3;
-        const float xv = (k < 3) ? v.z[a * DMAX + k] : 0.0f;
-        v.xs[tid] = xv;
-        v.x0[tid] = xv;
-    }
-    if (PREC == 1) {
-        float n2 = 0.0f;
-        if (tid < nb) {
-            const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
-            n2 = x0 * x0 + x1 * x1 + x2 * x2;
-        }
-        const unsigned b = wave_max_u32(__float_as_uint(n2));
-        if (lane == 0) { atomicMax(&v.fmax[FM_X2], b); atomicMax(&v.fmax[FM_X02], b); }
-    }
-    // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224)
-    {
-        const int f = tid & (HID - 1);
-        float wrow[FINP];
-        const float4* wsrc = reinterpret_cast<const float4*>(wp + OFF_EMB_W + f * FINP);
-#pragma unroll
-        for (int q = 0; q < FINP / 4; ++q) {
-            const float4 t4 = wsrc[q];
-            wrow[4 * q] = t4.x; wrow[4 * q + 1] = t4.y; wrow[4 * q + 2] = t4.z; wrow[4 * q + 3] = t4.w;
-        }
-        const float be = wp[OFF_EMB_B + f];
-        float hmax = 0.0f;
-        for (int a = tid >> 7; a < nb; a += THREADS / HID) {
-            float acc = be;
-#pragma unroll
-            for (int k = 0; k < FINP; ++k) {
-                float hin = 0.0f;
-                if (k < md.nf) hin = v.z[a * DMAX + 3 + k];
-                else if (k == md.nf) hin = tfeat;
-                else if (k < md.fin) hin = v.ctx[a * CTXMAX + (k - md.nf - 1)];
-                acc = fmaf(wrow[k], hin, acc);
-            }
-            v.C[a * LDH + f] = acc;
-            hmax = fmaxf(hmax, fabsf(acc));
-        }
-        if (PREC == 1) block_max(&v.fmax[FM_H0], hmax, lane);
-    }
-    __syncthreads();
-    for (int e = tid; e < nb * 32; e += THREADS)                   // the embedded rows: the first GCL's copy of h
-        *reinterpret_cast<float4*>(hs + (e >> 5) * HID + 4 * (e & 31)) = *reinterpret_cast<const float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31));
-    prof_event(pf, w, lane, 2);
-
-    int par = 0;
-    for (int blk = 0; blk < md.n_layers; ++blk) {
-        const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
-#pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const NextPass nx = {base + (gi + 1) * GCL_SIZE, gi == 1};
-            gcl_pass<PREC, TEAM>(v, nb, base + gi * GCL_SIZE, hs, emask, N, pf, par, pw, nx, md);
-        }
-        const NextPass nx = {blk + 1 < md.n_layers ? base + BLOCK_SIZE : nullptr, false};
-        equiv_pass<PREC, TEAM>(v, nb, base + 2 * GCL_SIZE, emask, N, md.norm_constant, pf, par, pw, nx, md);
-    }
-    prof_event(pf, w, lane, 3);
-
-    // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
-    float* eps = v.A;
-    int nanbits = 0;
-    for (int e = tid; e < nb * md.nf; e += THREADS) {
-        const int a = e / md.nf, o = e - a * md.nf;
-        const float4* hp = reinterpret_cast<const float4*>(v.C + a * LDH);
-        const float4* wo = reinterpret_cast<const float4*>(wp + OFF_OUT_W + o * HID);
-        float acc = wp[OFF_OUT_B + o];
-#pragma unroll 8
-        for (int q = 0; q < HID / 4; ++q) {
-            const float4 hv = hp[q], wv = wo[q];
-            acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc);
-            acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
-        }
-        eps[a * DMAX + 3 + o] = acc;
-        if (acc != acc) nanbits |= 2;
-    }
-    if (tid < 4 * nb && (tid & 3) < 3) {
-        const float vel = v.xs[tid] - v.x0[tid];
-        eps[(tid >> 2) * DMAX + (tid & 3)] = vel;
-        if (vel != vel) nanbits |= 1;
-    }
-    if (TEAM && tid == 0 && v.misc[TM_FAIL] != 0) nanbits |= 8;       // a team exchange timed out: the result is void
-    if (nanbits) atomicOr(&v.misc[1], nanbits);
-    __syncthreads();
-    prof_event(pf, w, lane, 4);
-}
-
-// the coordinate-pass receiver list from the linker mask in v.lm (n_b <= 55 atoms: one wave); visible after the next barrier
-__device__ __forceinline__ void build_receivers(const Lds& v, int nb, int tid) {
+// the coordinate-pass receiver list from the linker mask of the own atoms in v.lm (<= 55: one wave); visible after the next barrier
+__device__ __forceinline__ void build_receivers(const Lds& v, int nown, int tid) {
     if (tid < 64) {
-        const bool rec = tid < nb && v.lm[tid] != 0.0f;
+        const bool rec = tid < nown && v.lm[tid] != 0.0f;
         const unsigned long long bal = __ballot(rec);
         const int pos = __popcll(bal & ((1ull << tid) - 1ull));
         if (rec) v.rcv[pos] = tid;
@@ -1854,7 +1453,7 @@ __device__ __forceinline__ int compact_atoms(const Lds& v, const int8_t* __restr
             const bool real = (a < N) && (node_mask_b[a] != 0);
             const unsigned long long bal = __ballot(real);
             const int pos = count + __popcll(bal & ((1ull << tid) - 1ull));
-            if (real && pos < NMAX) v.idx[pos] = a;
+            if (real && pos < NQMAX) v.idx[pos] = a;
             count += __popcll(bal);
         }
         if (tid == 0) { v.misc[0] = count; v.misc[1] = 0; }
@@ -1864,7 +1463,10 @@ __device__ __forceinline__ int compact_atoms(const Lds& v, const int8_t* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Kernel 1: one Dynamics.forward per launch (src/egnn.py:374-447), one workgroup per molecule.
+// Kernels.  1: one Dynamics.forward per launch (src/egnn.py:374-447).  2: EDM.sample_chain (src/edm.py:126-242) - T reverse
+// steps + final decode in ONE launch.  TEAM = false: one workgroup per molecule (batches that fill the chip - the benchmarked
+// configuration); TEAM = true: a team of p.team workgroups per molecule.  Everything a phase needs is re-read from the LDS
+// context block or from the kernel arguments (scalar cache) where it is used.
 // ---------------------------------------------------------------------------------------------------
 struct FwdArgs {
     const float* wpack;
@@ -1880,10 +1482,11 @@ struct FwdArgs {
     float* out;
     int* nan_flags;
     unsigned long long* prof;
-    int team;                       // team kernels: workgroups per molecule, exchange rows [B][2][NMAX][HID], arrival words [B][TEAM_MAX]
-    float* team_rows;
+    int team;                       // team kernels: workgroups per molecule; exchange buffers [B][TEAM_MOL_BYTES], arrival words [B][TEAM_MAX]
+    int team_fault;                 // tests: member 1 gives up at once (dl_debug_team_fault)
+    char* team_rows;
     unsigned* team_flags;
-    float* hsave;                   // [workgroups][NMAX][HID]: the node features across the GCL pair loops (hsave_dma)
+    float* hsave;                   // [workgroups][HS_STRIDE]: per-workgroup HBM scratch of the per-atom phases
 };
 
 // Team kernels: workgroup k -> (molecule slot, member index).  The members of a team sit 8 workgroups apart, which is the
@@ -1900,217 +1503,20 @@ __device__ __forceinline__ TeamSlot team_slot(int k, int S) {
     return t;
 }
 // after compact_atoms (which ends with a barrier): the team block of v.misc; visible after the next barrier
-__device__ __forceinline__ void team_init(const Lds& v, int nb, int tid, int S, int rank, float* rows, unsigned* flags) {
-    if (tid == 0) {
-        const unsigned long long pr = reinterpret_cast<unsigned long long>(rows), pf = reinterpret_cast<unsigned long long>(flags);
-        v.misc[TM_EPOCH] = 0; v.misc[TM_FAIL] = 0;
-        v.misc[TM_ROWS] = int(unsigned(pr)); v.misc[TM_ROWS + 1] = int(unsigned(pr >> 32));
-        v.misc[TM_FLAGS] = int(unsigned(pf)); v.misc[TM_FLAGS + 1] = int(unsigned(pf >> 32));
-        v.misc[TM_S] = S; v.misc[TM_RANK] = rank;
-        const int r0 = (nb * rank) / S;
-        v.misc[TM_R0] = r0; v.misc[TM_NREC] = (nb * (rank + 1)) / S - r0;
-    }
+__device__ __forceinline__ void team_init(const Lds& v, int nb, int S, int rank, char* rows, unsigned* flags, int fault) {
+    const unsigned long long pr = reinterpret_cast<unsigned long long>(rows), pf = reinterpret_cast<unsigned long long>(flags);
+    v.misc[TM_EPOCH] = 0; v.misc[TM_FAIL] = (fault != 0 && rank == 1) ? 1 : 0;
+    v.misc[TM_ROWS] = int(unsigned(pr)); v.misc[TM_ROWS + 1] = int(unsigned(pr >> 32));
+    v.misc[TM_FLAGS] = int(unsigned(pf)); v.misc[TM_FLAGS + 1] = int(unsigned(pf >> 32));
+    v.misc[TM_S] = S; v.misc[TM_RANK] = rank;
+    v.misc[TM_NOWN] = nb > rank ? (nb - rank + S - 1) / S : 0;
+    v.misc[TM_XSLOT] = FM_X2;
 }
 
-template <int PREC, bool TEAM>
-__global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
-    const Lds v = lds_view(lds_raw);
-    const int tid = threadIdx.x;
-    int b = blockIdx.x, rank = 0;
-    if constexpr (TEAM) {
-        const TeamSlot ts = team_slot(blockIdx.x, p.team);
-        if (ts.slot >= p.B) return;
-        b = ts.slot; rank = ts.rank;
-    }
-    const bool writer = rank == 0;          // a team's copies are identical: its first member writes the results
-    const int N = p.N, D = 3 + p.md.nf;
-    const int8_t* nm = p.node_mask + size_t(b) * N;
-    float* out_b = p.out + size_t(b) * N * D;
-
-    const int nb = compact_atoms(v, nm, N, tid);
-    if constexpr (TEAM) team_init(v, nb, tid, p.team, rank, p.team_rows + size_t(b) * 2 * NMAX * HID, p.team_flags + size_t(b) * TEAM_MAX);
-    // padded rows of the output are exactly zero (node_mask multiply, egnn.py:420,236-237)
-    if (writer)
-        for (int e = tid; e < N * D; e += THREADS)
-            if (nm[e / D] == 0) out_b[e] = 0.0f;
-    if (nb > NMAX) {
-        if (writer) {
-            for (int e = tid; e < N * D; e += THREADS) out_b[e] = 0.0f;
-            if (tid == 0) p.nan_flags[b] = 4;
-        }
-        return;
-    }
-    if (nb == 0) {
-        if (writer && tid == 0) p.nan_flags[b] = 0;
-        return;
-    }
-    const float* xh_b = p.xh + size_t(b) * N * D;
-    for (int e = tid; e < nb * D; e += THREADS) {
-        const int a = e / D, d = e - a * D;
-        v.z[a * DMAX + d] = xh_b[v.idx[a] * D + d];
-    }
-    if (tid < nb) {
-        v.lm[tid] = p.linker_mask ? p.linker_mask[size_t(b) * N + v.idx[tid]] : 1.0f;
-        for (int k = 0; k < p.md.ctx; ++k)
-            v.ctx[tid * CTXMAX + k] = p.context[(size_t(b) * N + v.idx[tid]) * p.md.ctx + k];
-    }
-    __syncthreads();
-    build_receivers(v, nb, tid);
-    __syncthreads();
-    const float tfeat = p.t[size_t(b) * p.t_stride];
-    const int8_t* em = p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr;
-    Prof pf;
-    pf.buf = (b == 0 && rank == 0) ? p.prof : nullptr;
-    pf.n = 0;
-    forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, tfeat, em, N, pf, p.hsave + size_t(blockIdx.x) * HS_STRIDE);
-    if (!writer) return;
-    for (int e = tid; e < nb * D; e += THREADS) {
-        const int a = e / D, d = e - a * D;
-        out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
-    }
-    if (tid == 0) p.nan_flags[b] = v.misc[1];
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Kernel 2: EDM.sample_chain (src/edm.py:126-242) — T reverse steps + final decode in ONE launch.
-// ---------------------------------------------------------------------------------------------------
-struct ChainArgs {
-    const float* wpack;
-    ModelDims md;
-    dl_chain_args a;
-    unsigned long long* prof;
-    float* team_rows;               // team kernels: exchange rows [B][2][NMAX][HID], arrival words [B][TEAM_MAX] (inside a.team_ws)
-    unsigned* team_flags;
-    float* hsave;                   // [workgroups][NMAX][HID]: the node features across the GCL pair loops (hsave_dma)
-};
-
-template <int PREC, bool TEAM>
-__global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
-    __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
-    const Lds v = lds_view(lds_raw);
-    const dl_chain_args& g = p.a;
-    const int tid = threadIdx.x;
-    int k = blockIdx.x, rank = 0;
-    if constexpr (TEAM) {
-        const TeamSlot ts = team_slot(blockIdx.x, g.team);
-        if (ts.slot >= g.B) return;
-        k = ts.slot; rank = ts.rank;
-    }
-    const bool writer = rank == 0;          // a team's copies are identical: its first member writes the results
-    const int b = g.order ? g.order[k] : k;
-    const int N = g.N, nf = p.md.nf, D = 3 + nf, T = g.T, K = g.keep_frames, B = g.B;
-    const int8_t* nm = g.node_mask + size_t(b) * N;
-    const size_t frame = size_t(B) * N * D;
-    float* chain_b = g.chain + size_t(b) * N * D;
-
-    const int nb = compact_atoms(v, nm, N, tid);
-    if constexpr (TEAM) team_init(v, nb, tid, g.team, rank, p.team_rows + size_t(k) * 2 * NMAX * HID, p.team_flags + size_t(k) * TEAM_MAX);
-    if (writer) {
-        if (tid == 0) { g.nan_flags[b] = (nb > NMAX) ? 4 : 0; g.nan_step[b] = -1; }
-        // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
-        for (int kf = 0; kf < K; ++kf)
-            for (int e = tid; e < N * D; e += THREADS)
-                if (nm[e / D] == 0 || nb > NMAX) chain_b[kf * frame + e] = 0.0f;
-    }
-    if (nb > NMAX || nb == 0) return;
-
-    if (tid < nb) {
-        const size_t n = size_t(b) * N + v.idx[tid];
-        v.lm[tid] = g.linker_mask[n];
-        v.frag[tid] = g.fragment_mask[n];
-        for (int k = 0; k < p.md.ctx; ++k) v.ctx[tid * CTXMAX + k] = g.context[n * p.md.ctx + k];
-    }
-    __syncthreads();
-    build_receivers(v, nb, tid);
-    __syncthreads();
-    const bool philox = (g.noise_x == nullptr);                // draws generated in place (pack_layout.h: philox_normal)
-    const unsigned gmol = unsigned(g.mol_offset + (g.mol_index ? g.mol_index[b] : b));     // global molecule index: the noise key
-    // z = normalize(x,h) * fragment_mask + noise_0 * linker_mask   (edm.py:132-137,347-350)
-    for (int e = tid; e < nb * D; e += THREADS) {
-        const int a = e / D, d = e - a * D;
-        const size_t n = size_t(b) * N + v.idx[a];
-        float val, eps0;
-        if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = philox ? 0.0f : g.noise_x[n * 3 + d]; }
-        else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = philox ? 0.0f : g.noise_h[n * nf + d - 3]; }
-        if (philox) eps0 = philox_normal(g.noise_seed, gmol, unsigned(v.idx[a]), 0u, unsigned(d));
-        const float lm = v.lm[a];
-        v.z[a * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[a]), __fmul_rn(__fmul_rn(eps0, lm), lm));
-    }
-    __syncthreads();
-    const int8_t* em = g.edge_mask ? g.edge_mask + size_t(b) * N * N : nullptr;
-    const size_t nx_stride = size_t(B) * N * 3, nh_stride = size_t(B) * N * nf;
-
-    for (int q = 0; q <= T; ++q) {
-        const bool decode = (q == T);                          // last forward: p(x,h | z_0), edm.py:210-242
-        dl_step_coef cf;
-        if (decode) { cf.t = 0.0f; cf.alpha_ts = 1.0f; cf.c_eps = 0.0f; cf.sigma = 0.0f; }
-        else cf = g.coefs[q];
-        Prof pf;
-        pf.buf = (blockIdx.x == 0 && q == 0) ? p.prof : nullptr;
-        pf.n = 0;
-        forward_molecule<PREC, TEAM>(v, nb, tid, p.md, p.wpack, cf.t, em, N, pf, p.hsave + size_t(blockIdx.x) * HS_STRIDE);
-        if (v.misc[1] != 0) {                                  // FoundNaNException (egnn.py:441-442)
-            if (writer && tid == 0) { g.nan_flags[b] = v.misc[1]; g.nan_step[b] = q; }
-            return;
-        }
-        const int s = T - 1 - q;
-        const int widx = decode ? 0 : (s * K) / T;
-        const bool last_writer = (s == 0) || (((s - 1) * K) / T != widx);
-        const bool write = writer && !decode && last_writer && widx != 0;   // frame 0 is overwritten by the decode
-        for (int e = tid; e < nb * D; e += THREADS) {
-            const int a = e / D, d = e - a * D;
-            const size_t n = size_t(b) * N + v.idx[a];
-            const float lm = v.lm[a];
-            const float zt = v.z[a * DMAX + d];
-            const float eh = __fmul_rn(v.A[a * DMAX + d], lm);
-            float nz;
-            if (philox) nz = philox_normal(g.noise_seed, gmol, unsigned(v.idx[a]), unsigned(q + 1), unsigned(d));
-            else nz = (d < 3) ? g.noise_x[(q + 1) * nx_stride + n * 3 + d] : g.noise_h[(q + 1) * nh_stride + n * nf + d - 3];
-            float zn;
-            if (!decode) {
-                // z_s = z_t*frag + (z_t/alpha - c_eps*(eps*lm) + sigma*(noise*lm))*lm   (edm.py:196-206)
-                const float mu = __fsub_rn(__fdiv_rn(zt, cf.alpha_ts), __fmul_rn(cf.c_eps, eh));
-                const float zs = __fadd_rn(mu, __fmul_rn(cf.sigma, __fmul_rn(nz, lm)));
-                zn = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(zs, lm));
-                if (write) {                                   // chain[widx] = unnormalize_z(z) (edm.py:162-163)
-                    const float o = (d < 3) ? __fmul_rn(zn, g.norm_x) : __fadd_rn(__fmul_rn(zn, g.norm_h), g.bias_h);
-                    chain_b[widx * frame + v.idx[a] * D + d] = o;
-                }
-            } else {
-                // xh = z_0*frag + (1/alpha_0*(z_0 - sigma_0*eps) + sigma_x*(noise*lm))*lm, then unnormalize
-                const float mu = __fmul_rn(g.inv_alpha0, __fsub_rn(zt, __fmul_rn(g.sigma0, eh)));
-                const float xh = __fadd_rn(mu, __fmul_rn(g.sigma_x, __fmul_rn(nz, lm)));
-                const float zz = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(xh, lm));
-                zn = (d < 3) ? __fmul_rn(zz, g.norm_x) : __fadd_rn(__fmul_rn(zz, g.norm_h), g.bias_h);
-            }
-            v.z[a * DMAX + d] = zn;
-        }
-        __syncthreads();
-    }
-    if (writer && tid < nb) {
-        const int a = tid;
-        float* o = chain_b + v.idx[a] * D;
-        o[0] = v.z[a * DMAX + 0]; o[1] = v.z[a * DMAX + 1]; o[2] = v.z[a * DMAX + 2];
-        int best = 0;                                          // torch.argmax: first maximal index
-        float bv = v.z[a * DMAX + 3];
-        for (int k = 1; k < nf; ++k) {
-            const float hv = v.z[a * DMAX + 3 + k];
-            if (hv > bv) { bv = hv; best = k; }
-        }
-        for (int k = 0; k < nf; ++k) o[3 + k] = (k == best) ? 1.0f : 0.0f;   // one_hot * node_mask (=1 here)
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Kernels 1b / 2b: the same two entry points for ONE workgroup per molecule (batches that fill the chip - the benchmarked
-// configuration), on the per-atom phases version 2.  Everything a phase needs is re-read from the LDS context block or from the
-// kernel arguments (scalar cache) where it is used; the team kernels above keep round 2's code until they move over too.
-// ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void ctx_store(const Lds& v, const ModelDims& md, int N, const int8_t* em, float* hs, const float* wp,
-                                          float tfeat, int mol) {
+                                          const float* ctx_rows, float tfeat, int mol) {
     v.misc[CX_N] = N;
-    ctx_set_p(v, CX_EM, em); ctx_set_p(v, CX_HS, hs); ctx_set_p(v, CX_WP, wp);
+    ctx_set_p(v, CX_EM, em); ctx_set_p(v, CX_HS, hs); ctx_set_p(v, CX_WP, wp); ctx_set_p(v, CX_CTXP, ctx_rows);
     v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0;
     v.misc[CX_FLAGS] = (md.attention ? 1 : 0) | (md.tanh ? 2 : 0) | (md.mean ? 4 : 0);
     v.misc[CX_NORMC] = __float_as_int(md.norm_constant); v.misc[CX_CRANGE] = __float_as_int(md.coords_range);
@@ -2119,60 +1525,87 @@ __device__ __forceinline__ void ctx_store(const Lds& v, const ModelDims& md, int
     v.misc[CX_TFEAT] = __float_as_int(tfeat); v.misc[CX_MOL] = mol;
 }
 
-template <int PREC>
-__global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel2(FwdArgs p) {
+template <int PREC, bool TEAM>
+__global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
+    int b = blockIdx.x, rank = 0, S = 1;
+    if constexpr (TEAM) {
+        const TeamSlot ts = team_slot(blockIdx.x, p.team);
+        if (ts.slot >= p.B) return;
+        b = ts.slot; rank = ts.rank; S = p.team;
+    }
     {
         const int tid = threadIdx.x;
-        const int b = blockIdx.x;
         const int N = p.N, D = 3 + p.md.nf;
+        const int limit = TEAM ? NQMAX : NMAX;
         const int8_t* nm = p.node_mask + size_t(b) * N;
         float* out_b = p.out + size_t(b) * N * D;
         const int nb = compact_atoms(v, nm, N, tid);
         // padded rows of the output are exactly zero (node_mask multiply, egnn.py:420,236-237)
-        for (int e = tid; e < N * D; e += THREADS)
-            if (nm[e / D] == 0 || nb > NMAX) out_b[e] = 0.0f;
-        if (nb > NMAX || nb == 0) {
-            if (tid == 0) p.nan_flags[b] = (nb > NMAX) ? 4 : 0;
+        if (rank == 0)
+            for (int e = tid; e < N * D; e += THREADS)
+                if (nm[e / D] == 0 || nb > limit) out_b[e] = 0.0f;
+        if (nb > limit || nb == 0) {
+            if (rank == 0 && tid == 0) {
+                if (TEAM) { if (nb > limit) atomicOr(&p.nan_flags[b], 4); }
+                else p.nan_flags[b] = (nb > limit) ? 4 : 0;
+            }
             return;
         }
-        const float* xh_b = p.xh + size_t(b) * N * D;
-        for (int e = tid; e < nb * D; e += THREADS) {
-            const int a = e / D, d = e - a * D;
-            v.z[a * DMAX + d] = xh_b[v.idx[a] * D + d];
+        if (tid == 0) {
+            if (TEAM) team_init(v, nb, S, rank, p.team_rows + size_t(b) * TEAM_MOL_BYTES, p.team_flags + size_t(b) * TEAM_MAX, p.team_fault);
+            ctx_store(v, p.md, N, p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr, p.hsave + size_t(blockIdx.x) * HS_STRIDE,
+                      p.wpack, p.context ? p.context + size_t(b) * N * p.md.ctx : nullptr, p.t[size_t(b) * p.t_stride], b);
         }
-        if (tid < nb) {
-            v.lm[tid] = p.linker_mask ? p.linker_mask[size_t(b) * N + v.idx[tid]] : 1.0f;
-            for (int k = 0; k < p.md.ctx; ++k)
-                v.ctx[tid * CTXMAX + k] = p.context[(size_t(b) * N + v.idx[tid]) * p.md.ctx + k];
-        }
-        if (tid == 0)
-            ctx_store(v, p.md, N, p.edge_mask ? p.edge_mask + size_t(b) * N * N : nullptr, p.hsave + size_t(b) * HS_STRIDE, p.wpack,
-                      p.t[size_t(b) * p.t_stride], b);
         __syncthreads();
-        build_receivers(v, nb, tid);
+        const int nown = TEAM ? v.misc[TM_NOWN] : nb;
+        const float* xh_b = p.xh + size_t(b) * N * D;
+        for (int e = tid; e < nown * D; e += THREADS) {
+            const int l = e / D, d = e - l * D;
+            v.z[l * DMAX + d] = xh_b[v.idx[rank + l * S] * D + d];
+        }
+        if (tid < nown) v.lm[tid] = p.linker_mask ? p.linker_mask[size_t(b) * N + v.idx[rank + tid * S]] : 1.0f;
+        __syncthreads();
+        build_receivers(v, nown, tid);
         __syncthreads();
     }
     Prof pf;
     pf.buf = (blockIdx.x == 0) ? p.prof : nullptr;
     pf.n = 0;
-    forward_molecule2<PREC>(v, pf);
-    {   // results (arguments and sizes re-read: see the pass context)
+    forward_molecule2<PREC, TEAM>(v, pf);
+    {   // results of the own atoms (arguments and sizes re-read: see the pass context)
         const auto* P = kargs<FwdArgs>();
         const int tid = lane_ids().tid;
-        const int b = blockIdx.x, nb = ctx_i(v, 0), N = P->N, D = 3 + P->md.nf;
-        float* out_b = P->out + size_t(b) * N * D;
-        for (int e = tid; e < nb * D; e += THREADS) {
-            const int a = e / D, d = e - a * D;
-            out_b[v.idx[a] * D + d] = v.A[a * DMAX + d];
+        const int mol = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), N = P->N, D = 3 + P->md.nf;
+        const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+        const int S2 = TEAM ? ctx_i(v, TM_S) : 1, rank2 = TEAM ? ctx_i(v, TM_RANK) : 0;
+        float* out_b = P->out + size_t(mol) * N * D;
+        for (int e = tid; e < nown * D; e += THREADS) {
+            const int l = e / D, d = e - l * D;
+            out_b[v.idx[rank2 + l * S2] * D + d] = v.A[l * DMAX + d];
         }
-        if (tid == 0) P->nan_flags[b] = v.misc[1];
+        if (tid == 0) {
+            if (TEAM) { if (v.misc[1]) atomicOr(&P->nan_flags[mol], v.misc[1]); }
+            else P->nan_flags[mol] = v.misc[1];
+        }
     }
 }
 
-// one reverse step (or the final decode, q == T) of the molecule in LDS: denoiser, then the sampler algebra.  false: NaN, stop.
-template <int PREC>
+struct ChainArgs {
+    const float* wpack;
+    ModelDims md;
+    dl_chain_args a;
+    unsigned long long* prof;
+    char* team_rows;                // team kernels: exchange buffers [B][TEAM_MOL_BYTES], arrival words [B][TEAM_MAX] (inside a.workspace)
+    unsigned* team_flags;
+    int team_fault;                 // tests: member 1 gives up at once (dl_debug_team_fault)
+    float* hsave;                   // [workgroups][HS_STRIDE]: per-workgroup HBM scratch of the per-atom phases
+};
+
+// one reverse step (or the final decode, q == T) for the own atoms of the molecule in LDS: denoiser, then the sampler
+// algebra.  false: NaN, stop (one workgroup per molecule; a team goes on - its members must keep meeting - and only records it).
+template <int PREC, bool TEAM>
 __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     {
         const auto* P = kargs<ChainArgs>();
@@ -2186,14 +1619,22 @@ __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     Prof pf;
     pf.buf = (blockIdx.x == 0 && q == 0) ? kargs<ChainArgs>()->prof : nullptr;
     pf.n = 0;
-    forward_molecule2<PREC>(v, pf);
+    forward_molecule2<PREC, TEAM>(v, pf);
     const auto* P = kargs<ChainArgs>();
     const int tid = lane_ids().tid;
     const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0);
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+    const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
     const int N = P->a.N, nf = P->md.nf, D = 3 + nf, T = P->a.T, K = P->a.keep_frames, B = P->a.B;
     if (v.misc[1] != 0) {                                      // FoundNaNException (egnn.py:441-442)
-        if (tid == 0) { P->a.nan_flags[b] = v.misc[1]; P->a.nan_step[b] = q; }
-        return false;
+        if (!TEAM) {
+            if (tid == 0) { P->a.nan_flags[b] = v.misc[1]; P->a.nan_step[b] = q; }
+            return false;
+        }
+        if (tid == 0) {                                        // first offending forward of any member
+            atomicOr(&P->a.nan_flags[b], v.misc[1]);
+            atomicCAS(&P->a.nan_step[b], -1, q);
+        }
     }
     const bool decode = (q == T);
     dl_step_coef cf;
@@ -2201,6 +1642,7 @@ __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     else cf = P->a.coefs[q];
     const float* noise_x = P->a.noise_x;
     const float* noise_h = P->a.noise_h;
+    const float* fragm = P->a.fragment_mask;
     const bool philox = (noise_x == nullptr);
     const unsigned gmol = unsigned(P->a.mol_offset + (P->a.mol_index ? P->a.mol_index[b] : b));
     const unsigned long long seed = P->a.noise_seed;
@@ -2213,106 +1655,126 @@ __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     const int widx = decode ? 0 : (s * K) / T;
     const bool last_writer = (s == 0) || (((s - 1) * K) / T != widx);
     const bool write = !decode && last_writer && widx != 0;   // frame 0 is overwritten by the decode
-    for (int e = tid; e < nb * D; e += THREADS) {
-        const int a = e / D, d = e - a * D;
-        const size_t n = size_t(b) * N + v.idx[a];
-        const float lm = v.lm[a];
-        const float zt = v.z[a * DMAX + d];
-        const float eh = __fmul_rn(v.A[a * DMAX + d], lm);
+    for (int e = tid; e < nown * D; e += THREADS) {
+        const int l = e / D, d = e - l * D;
+        const int pos = v.idx[rank + l * S];
+        const size_t n = size_t(b) * N + pos;
+        const float lm = v.lm[l], fr = v.frag[l];
+        const float zt = v.z[l * DMAX + d];
+        const float eh = __fmul_rn(v.A[l * DMAX + d], lm);
         float nz;
-        if (philox) nz = philox_normal(seed, gmol, unsigned(v.idx[a]), unsigned(q + 1), unsigned(d));
+        if (philox) nz = philox_normal(seed, gmol, unsigned(pos), unsigned(q + 1), unsigned(d));
         else nz = (d < 3) ? noise_x[(q + 1) * nx_stride + n * 3 + d] : noise_h[(q + 1) * nh_stride + n * nf + d - 3];
         float zn;
         if (!decode) {
             // z_s = z_t*frag + (z_t/alpha - c_eps*(eps*lm) + sigma*(noise*lm))*lm   (edm.py:196-206)
             const float mu = __fsub_rn(__fdiv_rn(zt, cf.alpha_ts), __fmul_rn(cf.c_eps, eh));
             const float zs = __fadd_rn(mu, __fmul_rn(cf.sigma, __fmul_rn(nz, lm)));
-            zn = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(zs, lm));
+            zn = __fadd_rn(__fmul_rn(zt, fr), __fmul_rn(zs, lm));
             if (write) {                                   // chain[widx] = unnormalize_z(z) (edm.py:162-163)
                 const float o = (d < 3) ? __fmul_rn(zn, norm_x) : __fadd_rn(__fmul_rn(zn, norm_h), bias_h);
-                chain_b[widx * frame + v.idx[a] * D + d] = o;
+                chain_b[widx * frame + pos * D + d] = o;
             }
         } else {
             // xh = z_0*frag + (1/alpha_0*(z_0 - sigma_0*eps) + sigma_x*(noise*lm))*lm, then unnormalize
             const float mu = __fmul_rn(inv_alpha0, __fsub_rn(zt, __fmul_rn(sigma0, eh)));
             const float xh = __fadd_rn(mu, __fmul_rn(sigma_x, __fmul_rn(nz, lm)));
-            const float zz = __fadd_rn(__fmul_rn(zt, v.frag[a]), __fmul_rn(xh, lm));
+            const float zz = __fadd_rn(__fmul_rn(zt, fr), __fmul_rn(xh, lm));
             zn = (d < 3) ? __fmul_rn(zz, norm_x) : __fadd_rn(__fmul_rn(zz, norm_h), bias_h);
         }
-        v.z[a * DMAX + d] = zn;
+        v.z[l * DMAX + d] = zn;
     }
+    (void)fragm;
+    if (TEAM && tid == 0) v.misc[1] = 0;                       // the team goes on: later forwards report afresh (the first one is recorded)
     __syncthreads();
     return true;
 }
 
-template <int PREC>
-__global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel2(ChainArgs p) {
+template <int PREC, bool TEAM>
+__global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
     int T;
     {
         const dl_chain_args& g = p.a;
         const int tid = threadIdx.x;
-        const int k = blockIdx.x;
+        int k = blockIdx.x, rank = 0, S = 1;
+        if constexpr (TEAM) {
+            const TeamSlot ts = team_slot(blockIdx.x, g.team);
+            if (ts.slot >= g.B) return;
+            k = ts.slot; rank = ts.rank; S = g.team;
+        }
         const int b = g.order ? g.order[k] : k;
         const int N = g.N, nf = p.md.nf, D = 3 + nf, K = g.keep_frames, B = g.B;
+        const int limit = TEAM ? NQMAX : NMAX;
         T = g.T;
         const int8_t* nm = g.node_mask + size_t(b) * N;
         const size_t frame = size_t(B) * N * D;
         float* chain_b = g.chain + size_t(b) * N * D;
         const int nb = compact_atoms(v, nm, N, tid);
-        if (tid == 0) { g.nan_flags[b] = (nb > NMAX) ? 4 : 0; g.nan_step[b] = -1; }
-        // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
-        for (int kf = 0; kf < K; ++kf)
-            for (int e = tid; e < N * D; e += THREADS)
-                if (nm[e / D] == 0 || nb > NMAX) chain_b[kf * frame + e] = 0.0f;
-        if (nb > NMAX || nb == 0) return;
-        if (tid < nb) {
-            const size_t n = size_t(b) * N + v.idx[tid];
+        if (rank == 0) {
+            if (tid == 0) {
+                if (TEAM) { if (nb > limit) atomicOr(&g.nan_flags[b], 4); }      // (a team's flags start at 0 / -1: set by the host)
+                else { g.nan_flags[b] = (nb > limit) ? 4 : 0; g.nan_step[b] = -1; }
+            }
+            // padded rows of every frame are zero (z is masked; chain starts from torch.zeros, edm.py:143)
+            for (int kf = 0; kf < K; ++kf)
+                for (int e = tid; e < N * D; e += THREADS)
+                    if (nm[e / D] == 0 || nb > limit) chain_b[kf * frame + e] = 0.0f;
+        }
+        if (nb > limit || nb == 0) return;
+        if (tid == 0) {
+            if (TEAM) team_init(v, nb, S, rank, p.team_rows + size_t(k) * TEAM_MOL_BYTES, p.team_flags + size_t(k) * TEAM_MAX, p.team_fault);
+            ctx_store(v, p.md, N, g.edge_mask ? g.edge_mask + size_t(b) * N * N : nullptr, p.hsave + size_t(blockIdx.x) * HS_STRIDE,
+                      p.wpack, g.context ? g.context + size_t(b) * N * p.md.ctx : nullptr, 0.0f, b);
+        }
+        __syncthreads();
+        const int nown = TEAM ? v.misc[TM_NOWN] : nb;
+        if (tid < nown) {
+            const size_t n = size_t(b) * N + v.idx[rank + tid * S];
             v.lm[tid] = g.linker_mask[n];
             v.frag[tid] = g.fragment_mask[n];
-            for (int kk = 0; kk < p.md.ctx; ++kk) v.ctx[tid * CTXMAX + kk] = g.context[n * p.md.ctx + kk];
         }
-        if (tid == 0)
-            ctx_store(v, p.md, N, g.edge_mask ? g.edge_mask + size_t(b) * N * N : nullptr, p.hsave + size_t(k) * HS_STRIDE, p.wpack,
-                      0.0f, b);
         __syncthreads();
-        build_receivers(v, nb, tid);
-        __syncthreads();
+        build_receivers(v, nown, tid);
         const bool philox = (g.noise_x == nullptr);                // draws generated in place (pack_layout.h: philox_normal)
         const unsigned gmol = unsigned(g.mol_offset + (g.mol_index ? g.mol_index[b] : b));     // global molecule index: the noise key
         // z = normalize(x,h) * fragment_mask + noise_0 * linker_mask   (edm.py:132-137,347-350)
-        for (int e = tid; e < nb * D; e += THREADS) {
-            const int a = e / D, d = e - a * D;
-            const size_t n = size_t(b) * N + v.idx[a];
+        for (int e = tid; e < nown * D; e += THREADS) {
+            const int l = e / D, d = e - l * D;
+            const int pos = v.idx[rank + l * S];
+            const size_t n = size_t(b) * N + pos;
             float val, eps0;
             if (d < 3) { val = __fdiv_rn(g.x[n * 3 + d], g.norm_x); eps0 = philox ? 0.0f : g.noise_x[n * 3 + d]; }
             else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = philox ? 0.0f : g.noise_h[n * nf + d - 3]; }
-            if (philox) eps0 = philox_normal(g.noise_seed, gmol, unsigned(v.idx[a]), 0u, unsigned(d));
-            const float lm = v.lm[a];
-            v.z[a * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[a]), __fmul_rn(__fmul_rn(eps0, lm), lm));
+            if (philox) eps0 = philox_normal(g.noise_seed, gmol, unsigned(pos), 0u, unsigned(d));
+            const float lm = v.lm[l];
+            v.z[l * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[l]), __fmul_rn(__fmul_rn(eps0, lm), lm));
         }
         __syncthreads();
     }
 #pragma nounroll
     for (int q = 0; q <= T; ++q)
-        if (!chain_step2<PREC>(v, q)) return;
-    {   // frame 0: the final sample [x, one_hot(h)]
+        if (!chain_step2<PREC, TEAM>(v, q)) return;
+    {   // frame 0: the final sample [x, one_hot(h)] of the own atoms
         const auto* P = kargs<ChainArgs>();
         const int tid = lane_ids().tid;
         const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), nf = P->md.nf, D = 3 + nf;
-        if (tid < nb) {
-            const int a = tid;
-            float* o = P->a.chain + size_t(b) * P->a.N * D + v.idx[a] * D;
-            o[0] = v.z[a * DMAX + 0]; o[1] = v.z[a * DMAX + 1]; o[2] = v.z[a * DMAX + 2];
+        const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+        const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
+        if (tid < nown) {
+            const int l = tid;
+            float* o = P->a.chain + size_t(b) * P->a.N * D + v.idx[rank + l * S] * D;
+            o[0] = v.z[l * DMAX + 0]; o[1] = v.z[l * DMAX + 1]; o[2] = v.z[l * DMAX + 2];
             int best = 0;                                          // torch.argmax: first maximal index
-            float bv = v.z[a * DMAX + 3];
+            float bv = v.z[l * DMAX + 3];
             for (int kk = 1; kk < nf; ++kk) {
-                const float hv = v.z[a * DMAX + 3 + kk];
+                const float hv = v.z[l * DMAX + 3 + kk];
                 if (hv > bv) { bv = hv; best = kk; }
             }
             for (int kk = 0; kk < nf; ++kk) o[3 + kk] = (kk == best) ? 1.0f : 0.0f;   // one_hot * node_mask (=1 here)
         }
+        if (TEAM && tid == 0 && v.misc[TM_FAIL] != 0) atomicOr(&P->a.nan_flags[b], 8);
     }
 }
 
@@ -2337,6 +1799,7 @@ __global__ void sampler_step_kernel(int total, int D, const float* __restrict__ 
 // Host side: weight packing and the C ABI
 // ---------------------------------------------------------------------------------------------------
 thread_local int g_last_hip = 0;
+int g_team_fault = 0;                       // tests only (dl_debug_team_fault): member 1 of every team gives up at its first exchange
 unsigned long long* g_prof_buf = nullptr;   // diagnostics only (dl_set_profile_buffer)
 
 inline bool hip_ok(hipError_t e) {
@@ -2489,6 +1952,7 @@ int32_t dl_profile_max_events(void) { return 0; }      // the phase timeline exi
 void dl_set_profile_buffer(void* device_buf) { g_prof_buf = static_cast<unsigned long long*>(device_buf); }
 int32_t dl_last_hip_error(void) { return g_last_hip; }
 int32_t dl_max_atoms(void) { return NMAX; }
+void dl_debug_team_fault(int32_t on) { g_team_fault = on; }
 
 const char* dl_error_string(int32_t s) {
     switch (s) {
@@ -2642,11 +2106,11 @@ void dl_model_destroy(dl_model* m) {
     free(m);
 }
 
-// ---- workspace (caller-owned, sized by dl_workspace_bytes): [h rows of every workgroup][team exchange rows][arrival words]
-// and launch geometry.  The library allocates nothing after dl_model_create.
+// ---- workspace (caller-owned, sized by dl_workspace_bytes): [HBM scratch of every workgroup][team exchange buffers][arrival
+// words] and launch geometry.  The library allocates nothing after dl_model_create.
 static int fc_grid(int32_t B, int32_t team) { return team <= 1 ? B : (B + 7) / 8 * 8 * team; }
 static size_t hsave_bytes(int32_t B, int32_t team) { return size_t(fc_grid(B, team)) * HS_STRIDE * sizeof(float); }
-static size_t team_rows_bytes(int32_t B) { return size_t(B) * 2 * TEAM_ROW_BYTES; }
+static size_t team_rows_bytes(int32_t B) { return size_t(B) * TEAM_MOL_BYTES; }
 
 size_t dl_workspace_bytes(int32_t B, int32_t team) {
     if (B <= 0 || team < 0 || team > TEAM_MAX) return 0;
@@ -2655,6 +2119,11 @@ size_t dl_workspace_bytes(int32_t B, int32_t team) {
     return n;
 }
 
+int32_t dl_team_max_atoms(int32_t team) { return team >= 2 ? NQMAX : NMAX; }
+
+// Largest team (1, 2, 4 or 8 workgroups per molecule) the current device holds for a batch of B with every workgroup
+// resident at once.  One compute unit in eight is left alone (a margin: the launch fails safe, but a co-tenant kernel on a
+// few compute units should not push the default path there).
 int32_t dl_team_max(int32_t B) {
     if (B <= 0) return 1;
     int dev = 0, cus = 0;
@@ -2669,7 +2138,7 @@ int32_t dl_team_max(int32_t B) {
 // splits the caller's workspace; for a team request validates it and zeroes the arrival words on `stream`
 struct FcWorkspace {
     float* hsave;
-    float* rows;
+    char* rows;
     unsigned* flags;
     int grid;
 };
@@ -2683,11 +2152,20 @@ static int32_t fc_workspace(int32_t B, int32_t team, void* ws, size_t ws_bytes, 
     out->rows = nullptr; out->flags = nullptr;
     if (team > 1) {
         char* p = static_cast<char*>(ws) + hsave_bytes(B, team);
-        out->rows = reinterpret_cast<float*>(p);
+        out->rows = p;
         out->flags = reinterpret_cast<unsigned*>(p + team_rows_bytes(B));
         if (!hip_ok(hipMemsetAsync(out->flags, 0, size_t(B) * TEAM_MAX * sizeof(unsigned), stream))) return DL_ERR_HIP;
     }
     return DL_OK;
+}
+
+// A team's workgroups wait for each other inside the launch: all of them must be resident at once.  The cooperative launch
+// checks the grid against the occupancy of the kernel on this device and fails (hipErrorCooperativeLaunchTooLarge) instead of
+// starting a launch that could not assemble; what it cannot see - another stream or process holding compute units - ends in
+// the bounded wait of team_sync and flag bit 3.
+static hipError_t launch_team(const void* kernel, int grid, hipStream_t st, void* args) {
+    void* params[] = {args};
+    return hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(THREADS), params, 0, st);
 }
 
 int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
@@ -2705,16 +2183,17 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
     FcWorkspace ws;
     const int32_t rc = fc_workspace(B, team, workspace, workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
-    a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave;
+    a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
     const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
     if (team <= 1) {
-        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel2<1>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((egnn_forward_fc_kernel2<0>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-    } else {
-        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
     }
-    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+    if (!hip_ok(hipMemsetAsync(nan_flags, 0, size_t(B) * sizeof(int32_t), st))) return DL_ERR_HIP;     // the members OR their bits in
+    const hipError_t e = f16 ? launch_team(reinterpret_cast<const void*>(&egnn_forward_fc_kernel<1, true>), ws.grid, st, &a)
+                             : launch_team(reinterpret_cast<const void*>(&egnn_forward_fc_kernel<0, true>), ws.grid, st, &a);
+    return hip_ok(e) ? DL_OK : DL_ERR_HIP;
 }
 
 int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
@@ -2739,17 +2218,19 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     FcWorkspace ws;
     const int32_t rc = fc_workspace(g->B, g->team, g->workspace, g->workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
-    a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave;
+    a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
     const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
     if (g->team <= 1) {
         a.a.team = 1;
-        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel2<1>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((sample_chain_fc_kernel2<0>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-    } else {
-        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, true>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
+        return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
     }
-    return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+    if (!hip_ok(hipMemsetAsync(g->nan_flags, 0, size_t(g->B) * sizeof(int32_t), st)) ||
+        !hip_ok(hipMemsetAsync(g->nan_step, 0xFF, size_t(g->B) * sizeof(int32_t), st))) return DL_ERR_HIP;
+    const hipError_t e = f16 ? launch_team(reinterpret_cast<const void*>(&sample_chain_fc_kernel<1, true>), ws.grid, st, &a)
+                             : launch_team(reinterpret_cast<const void*>(&sample_chain_fc_kernel<0, true>), ws.grid, st, &a);
+    return hip_ok(e) ? DL_OK : DL_ERR_HIP;
 }
 
 namespace {

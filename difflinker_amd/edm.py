@@ -248,12 +248,7 @@ class EDM(torch.nn.Module):
         else:
             assert keep_frames <= self.T
         bs, n = x.size(0), x.size(1)
-        big = None
-        if self._fused_ok() and n > _lib.load().dl_max_atoms():
-            big = node_mask.reshape(bs, n).ne(0).sum(1) > _lib.load().dl_max_atoms()     # molecules beyond the LDS-resident limit
-            if not bool(big.any()):
-                big = None
-        if not self._fused_ok() or (big is not None and bool(big.all())):
+        if not self._fused_ok():
             philox_draws = None
             if noise_bank is None and self.noise_source == 'philox':
                 philox_draws = (int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset))   # one draw per step, no bank
@@ -274,14 +269,24 @@ class EDM(torch.nn.Module):
             noise_bank = tuple(t.to(dev, torch.float32).contiguous() for t in noise_bank)
             assert tuple(noise_bank[0].shape) == (self.T + 2, bs, n, self.n_dims) and \
                 tuple(noise_bank[1].shape) == (self.T + 2, bs, n, self.in_node_nf)
-        if big is None:
+        # the draws are fixed by now: should a team of workgroups fail to assemble (another kernel holding compute units), the
+        # same chain is sampled again on one compute unit per molecule - nothing but FoundNaNException reaches the caller
+        return self.dynamics.without_teams(lambda: self._sample_chain_by_size(
+            x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames, noise_bank, philox, seed, mol_offset))
+
+    def _sample_chain_by_size(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames, noise_bank,
+                              philox, seed, mol_offset):
+        """Molecules of <= 55 atoms: the fused chain with one compute unit (or a team) per molecule; up to 110: the fused chain
+        with a team of at least two, in pieces the chip holds at once; beyond: the HBM-resident kernels under a host-driven
+        loop.  Noise rows and per-step scalars are those of the WHOLE batch, so every molecule gets the sample it would get
+        from any of the paths alone."""
+        bs, n = x.size(0), x.size(1)
+        dev = x.device
+        dyn = self.dynamics
+        small, med, big = dyn.size_classes(node_mask.reshape(bs, n).to(torch.int8))
+        if small is None and med is None and big is None:
             return self._sample_chain_fused(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames,
                                             noise_bank, seed, mol_offset, None)
-        # A batch with SOME molecules beyond the LDS-resident limit: those alone take the HBM-resident kernels and the
-        # host-driven loop, the rest the fused chain; noise rows and per-step scalars are those of the whole batch, so every
-        # molecule gets the sample it would get from either path alone.
-        idx_b = torch.nonzero(big).flatten()
-        idx_s = torch.nonzero(~big).flatten()
         em = edge_mask.reshape(bs, n * n) if edge_mask is not None else None
 
         def part(idx):
@@ -292,23 +297,27 @@ class EDM(torch.nn.Module):
         if pinned is None:
             self.coef_batch = bs
         try:
-            bank_s = bank_b = None
-            if not philox:
-                bank_s = (noise_bank[0][:, idx_s].contiguous(), noise_bank[1][:, idx_s].contiguous())
-                bank_b = (noise_bank[0][:, idx_b], noise_bank[1][:, idx_b])
-            small = self._sample_chain_fused(keep_frames=keep_frames, noise_bank=bank_s, seed=seed, mol_offset=mol_offset,
-                                             mol_index=idx_s.to(torch.int32).contiguous(), **part(idx_s))
-            large = self._sample_chain_host_loop(keep_frames=keep_frames, noise_bank=bank_b,
-                                                 philox_draws=(seed, int(mol_offset), idx_b, bs) if philox else None, **part(idx_b))
+            chain = torch.zeros((keep_frames, bs, n, self.n_dims + self.in_node_nf), device=dev)
+            fused = []
+            if small is not None:
+                fused.append((small, None))
+            if med is not None:
+                fused += [(c, max(2, dyn.team_for_size(int(c.numel()), dev))) for c in dyn.team_chunks(med, dev)]
+            for idx, team in fused:
+                bank = None if philox else (noise_bank[0][:, idx].contiguous(), noise_bank[1][:, idx].contiguous())
+                chain[:, idx] = self._sample_chain_fused(keep_frames=keep_frames, noise_bank=bank, seed=seed, mol_offset=mol_offset,
+                                                         mol_index=idx.to(torch.int32).contiguous(), team=team, **part(idx))
+            if big is not None:
+                bank = None if philox else (noise_bank[0][:, big], noise_bank[1][:, big])
+                large = self._sample_chain_host_loop(keep_frames=keep_frames, noise_bank=bank,
+                                                     philox_draws=(seed, int(mol_offset), big, bs) if philox else None, **part(big))
+                chain[:, big] = large.to(chain.dtype)
         finally:
             self.coef_batch = pinned
-        chain = torch.zeros((keep_frames, bs, n, self.n_dims + self.in_node_nf), device=dev)
-        chain[:, idx_s] = small
-        chain[:, idx_b] = large.to(chain.dtype)
         return chain
 
     def _sample_chain_fused(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames, noise_bank,
-                            seed, mol_offset, mol_index):
+                            seed, mol_offset, mol_index, team=None):
         """The whole chain as ONE launch (``dl_sample_chain_fc``).  ``noise_bank`` = device tensors, or None: draws generated
         in the kernel from ``seed`` and the molecules' global indices ``mol_offset + mol_index[b]`` (``mol_index`` None: b)."""
         dev = x.device
@@ -333,7 +342,9 @@ class EDM(torch.nn.Module):
         flags = torch.zeros(bs, dtype=torch.int32, device=dev)
         steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
         # a batch smaller than the chip: several compute units per molecule (Dynamics.team)
-        team = self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)), dev)
+        if team is None:
+            team = 1 if self.dynamics._no_teams else \
+                self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)), dev)
         ws, ws_bytes = self.dynamics.workspace(bs, team, dev)
         args = _lib.DLChainArgs(
             B=bs, N=n, T=T, keep_frames=keep_frames,
@@ -383,11 +394,10 @@ class EDM(torch.nn.Module):
         if bool(flags.any()):
             f, st = flags.cpu(), steps.cpu()
             if bool((f & 8).any()):
-                raise RuntimeError('a team of workgroups did not assemble in time (another kernel held compute units): '
-                                   'sample void; retry or set Dynamics.team = 1')
+                from .egnn import TeamNotAssembled
+                raise TeamNotAssembled('a team of workgroups did not assemble in time (another kernel held compute units)')
             if bool((f & 4).any()):
-                raise ValueError(f'molecule with more than {_lib.load().dl_max_atoms()} real atoms: '
-                                 'outside the LDS-resident fully-connected kernel')
+                raise ValueError('molecule with more real atoms than the LDS-resident fully-connected kernels take')
             first = int(st[f != 0].min())
             raise utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
 
@@ -532,6 +542,15 @@ class InpaintingEDM(EDM):
         else:
             noise_x, noise_h = (t_.to(dev, torch.float32).contiguous() for t_ in noise_bank)
             assert noise_x.shape[0] == 1 + 2 * T + 2
+        # (the draws are fixed: a team of workgroups that cannot assemble means one more run on one compute unit per molecule)
+        return self.dynamics.without_teams(lambda: self._inpaint_chain(x, h, node_mask, edge_mask, fragment_mask, linker_mask, context,
+                                                                       keep_frames, noise_x, noise_h))
+
+    def _inpaint_chain(self, x, h, node_mask, edge_mask, fragment_mask, linker_mask, context, keep_frames, noise_x, noise_h):
+        lib = _lib.load()
+        dev = x.device
+        bs, n = x.size(0), x.size(1)
+        nf, T = self.in_node_nf, self.T
         f32 = lambda t_, shape: t_.reshape(shape).to(torch.float32).contiguous()      # noqa: E731
         nm, fm, lm = f32(node_mask, (bs, n)), f32(fragment_mask, (bs, n)), f32(linker_mask, (bs, n))
         xn, hn = self.normalize(x, h)

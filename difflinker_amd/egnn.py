@@ -21,6 +21,11 @@ import torch.nn as nn
 from . import _lib, utils
 
 
+class TeamNotAssembled(RuntimeError):
+    """Internal: a team of workgroups did not get all its members resident in time (``nan_flags`` bit 3).  Never reaches a
+    caller: ``Dynamics.forward`` / ``EDM.sample_chain`` re-run the call on a path that needs no co-residency."""
+
+
 class _ParamOnly(nn.Module):
     """Parameter container: its arithmetic lives in the HIP kernels."""
 
@@ -211,6 +216,7 @@ class Dynamics(nn.Module):
         self.team = os.environ.get('DIFFLINKER_TEAM', 'auto')
         self._fc_ws = None
         self._team_auto = {}
+        self._no_teams = False                         # set while a call is re-run after a team failed to assemble
 
     # ---- packed weights -----------------------------------------------------------------------------
     def _weight_version(self):
@@ -265,35 +271,83 @@ class Dynamics(nn.Module):
         return self.attention or self.tanh or self.aggregation_method != 'sum'
 
     def fits_lds(self, node_mask):
-        """True when every molecule fits the LDS-resident kernels (<= ``dl_max_atoms()`` real atoms).  Bigger batches run
-        on the HBM-resident per-pass kernels (``dl_egnn_forward_fc_large``): same numbers, several times slower."""
+        """True when every molecule fits the LDS-resident kernels: <= ``dl_max_atoms()`` real atoms on one compute unit, <=
+        ``dl_team_max_atoms(2)`` on a team of them.  Bigger ones run on the HBM-resident per-pass kernels
+        (``dl_egnn_forward_fc_large``): same numbers, several times slower."""
         n_nodes = node_mask.shape[1]
-        limit = _lib.load().dl_max_atoms()
+        limit = self._atom_limit()
         return n_nodes <= limit or int(node_mask.reshape(node_mask.shape[0], n_nodes).ne(0).sum(1).max()) <= limit
+
+    def _atom_limit(self):
+        lib = _lib.load()
+        return int(lib.dl_max_atoms()) if self._no_teams else int(lib.dl_team_max_atoms(2))
+
+    def size_classes(self, nm):
+        """Index tensors (small, medium, big) of a batch by real-atom count: one compute unit per molecule possible / a team
+        needed / beyond the LDS-resident kernels.  ``None`` for an empty class; no host sync when the padded width already
+        says 'all small'."""
+        lim1 = int(_lib.load().dl_max_atoms())
+        if nm.shape[1] <= lim1:
+            return None, None, None                     # every molecule is small: the whole batch, no index tensors
+        sizes = nm.ne(0).sum(1)
+        lim2 = self._atom_limit()
+        small, big = sizes <= lim1, sizes > lim2
+        med = ~small & ~big
+        pick = lambda m: torch.nonzero(m).flatten() if bool(m.any()) else None      # noqa: E731
+        return pick(small), pick(med), pick(big)
+
+    def team_chunks(self, idx, device):
+        """Molecules that need a team (more atoms than one compute unit holds): pieces of the batch small enough for teams of
+        at least two workgroups to be resident at once."""
+        cap = int(idx.numel())
+        while int(self.team_for_size(cap, device)) < 2 and cap > 8:
+            cap = (cap + 1) // 2
+        return [idx[k:k + cap] for k in range(0, int(idx.numel()), cap)]
+
+    def team_for_size(self, batch_size, device):
+        """``dl_team_max`` for a batch size on ``device`` (cached)."""
+        saved, self.team = self.team, 'auto'
+        try:
+            return self.team_for(batch_size, device)
+        finally:
+            self.team = saved
 
     def prepare(self, node_mask, linker_mask, edge_mask, context):
         """Everything of a call that does not change along a sampling chain (mask conversions, the size check that picks
         the kernel family); ``launch`` then only enqueues kernels."""
         dev = node_mask.device
         bs, n_nodes = node_mask.shape[0], node_mask.shape[1]
-        prep = dict(bs=bs, n=n_nodes, dev=dev, large=False, handle=self.hip_model(dev),
+        prep = dict(bs=bs, n=n_nodes, dev=dev, large=False, team=None, handle=self.hip_model(dev),
                     nm=node_mask.reshape(bs, n_nodes).to(torch.int8).contiguous(),
                     lm=self._f32(linker_mask.reshape(bs, n_nodes)) if linker_mask is not None else None,
                     em=edge_mask.reshape(bs, n_nodes, n_nodes).to(torch.int8).contiguous() if edge_mask is not None else None,
                     ctx=self._f32(context.reshape(bs, n_nodes, self.context_node_nf)) if context is not None else None,
                     node_mask3=node_mask.reshape(bs, n_nodes, 1))
-        limit = _lib.load().dl_max_atoms()
-        if type(self) is Dynamics and n_nodes > limit:
-            big = prep['nm'].ne(0).sum(1) > limit                  # molecules beyond the LDS-resident kernels
-            if bool(big.all()):
-                prep['large'] = True
-            elif bool(big.any()):
-                # a mixed batch: only the big molecules take the HBM-resident kernels; `launch` runs both parts and scatters
-                def part(idx, large):
-                    sub = {k: (v[idx].contiguous() if torch.is_tensor(v) else v) for k, v in prep.items()}
-                    sub.update(bs=int(idx.numel()), large=large, idx=idx)
-                    return sub
-                prep['split'] = (part(torch.nonzero(~big).flatten(), False), part(torch.nonzero(big).flatten(), True))
+        if type(self) is not Dynamics:
+            return prep
+        small, med, big = self.size_classes(prep['nm'])
+        if small is None and med is None and big is None:
+            return prep
+
+        def part(idx, large, team=None):
+            sub = {k: (v[idx].contiguous() if torch.is_tensor(v) else v) for k, v in prep.items()}
+            sub.update(bs=int(idx.numel()), large=large, idx=idx, team=team)
+            return sub
+        parts = []
+        if small is not None:
+            parts.append(part(small, False))
+        if med is not None:                                        # a team per molecule, at least two workgroups
+            for chunk in self.team_chunks(med, dev):
+                parts.append(part(chunk, False, team=max(2, self.team_for_size(int(chunk.numel()), dev))))
+        if big is not None:
+            if self._flags():
+                raise NotImplementedError('attention / tanh / mean aggregation are not carried by the HBM-resident kernels that '
+                                          f'molecules of more than {self._atom_limit()} atoms run on')
+            parts.append(part(big, True))
+        if len(parts) == 1 and parts[0]['bs'] == bs:               # one class only: no scatter needed
+            prep.update(large=parts[0]['large'], team=parts[0]['team'])
+        else:
+            prep['split'] = parts
         return prep
 
     def launch(self, prep, t, xh, center=True):
@@ -316,7 +370,7 @@ class Dynamics(nn.Module):
         lib = _lib.load()
         dev = xh.device
         bs, n_nodes = xh.shape[0], xh.shape[1]
-        if prep is not None and prep.get('split') is not None:     # molecules on both sides of the LDS-resident limit
+        if prep is not None and prep.get('split') is not None:     # molecules of several size classes
             out = torch.zeros_like(self._f32(xh))
             flags = torch.zeros(bs, dtype=torch.int32, device=dev)
             t_rows = t.to(dev).reshape(-1) if torch.is_tensor(t) and t.numel() == bs and bs > 1 else None
@@ -345,7 +399,9 @@ class Dynamics(nn.Module):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
             if not large:
-                team = self.team_for(bs, dev)
+                team = prep.get('team') if prep is not None else None
+                if team is None:
+                    team = 1 if self._no_teams else self.team_for(bs, dev)
                 ws, need = self.workspace(bs, team, dev)
                 _lib.check(lib.dl_egnn_forward_fc_team(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
                                                        _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),
@@ -399,12 +455,24 @@ class Dynamics(nn.Module):
         if bool(flags.any()):
             f = flags.cpu()
             if bool((f & 8).any()):
-                raise RuntimeError('a team of workgroups did not assemble in time (another kernel held compute units): '
-                                   'sample void; retry or set Dynamics.team = 1')
+                raise TeamNotAssembled('a team of workgroups did not assemble in time (another kernel held compute units)')
             if bool((f & 4).any()):
-                raise ValueError(f'molecule with more than {_lib.load().dl_max_atoms()} real atoms: '
-                                 'outside the LDS-resident fully-connected kernel')
+                raise ValueError('molecule with more real atoms than the LDS-resident fully-connected kernels take '
+                                 f'({_lib.load().dl_max_atoms()} on one compute unit, {_lib.load().dl_team_max_atoms(2)} on a team)')
             raise utils.FoundNaNException.from_flags(f)
+
+    def without_teams(self, fn):
+        """Run ``fn()``; if a team of workgroups could not assemble (another kernel held compute units for seconds), run it
+        once more with one compute unit per molecule (molecules that need a team: on the HBM-resident kernels) - the
+        reference's callers catch ``FoundNaNException`` only (generate.py:154-161), nothing else may reach them."""
+        try:
+            return fn()
+        except TeamNotAssembled:
+            saved, self._no_teams = self._no_teams, True
+            try:
+                return fn()
+            finally:
+                self._no_teams = saved
 
     def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
         """
@@ -413,9 +481,13 @@ class Dynamics(nn.Module):
         Returns eps_hat (B, N, 3 + nf) = cat[vel, h_final]; raises ``utils.FoundNaNException``.
         """
         assert self.graph_type == 'FC'
-        prep = self.prepare(node_mask, linker_mask, edge_mask, context)
-        out, flags = self._launch_forward(t, xh, None, None, None, None, large=prep['large'], prep=prep)
-        self._raise_on_flags(flags)
+
+        def run():
+            prep = self.prepare(node_mask, linker_mask, edge_mask, context)
+            out, flags = self._launch_forward(t, xh, None, None, None, None, large=prep['large'], prep=prep)
+            self._raise_on_flags(flags)
+            return out
+        out = self.without_teams(run)
         if self.centering:                                     # inpainting only (egnn.py:444-445)
             nm = node_mask.reshape(xh.shape[0], xh.shape[1], 1).to(out.dtype)
             vel = utils.remove_mean_with_mask(out[:, :, :self.n_dims], nm)

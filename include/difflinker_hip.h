@@ -20,7 +20,7 @@
  *                                           (+ :178-208 reverse step, :210-242 final decode,
  *                                            :328-361 noise / (un)normalisation)
  *   dl_workspace_bytes                   <- (no reference counterpart) scratch the fully-connected entry points need
- *   dl_egnn_forward_fc_team, dl_team_max
+ *   dl_egnn_forward_fc_team, dl_team_max, dl_team_max_atoms
  *                                        <- the same Dynamics.forward / EDM.sample_chain with several compute
  *                                           units per molecule (batches smaller than the chip; no reference
  *                                           counterpart: a launch-geometry knob, results agree to fp32 rounding)
@@ -116,7 +116,8 @@ int32_t dl_model_num_tensors(const dl_config* cfg);
 int32_t dl_model_create(const dl_config* cfg, const float* const* weights, int32_t n_tensors, dl_model** out);
 void dl_model_destroy(dl_model* m);
 
-/* Largest number of REAL atoms per molecule the LDS-resident fully-connected kernel takes. */
+/* Largest number of REAL atoms per molecule the LDS-resident fully-connected kernels take with ONE workgroup per molecule
+ * (a team of workgroups: dl_team_max_atoms). */
 int32_t dl_max_atoms(void);
 
 /* Dynamics.forward, fully-connected graph (src/egnn.py:374-447).
@@ -139,8 +140,8 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* Scratch of dl_egnn_forward_fc / dl_egnn_forward_fc_team / dl_sample_chain_fc for a batch of B molecules with `team`
- * compute units per molecule (0 or 1: one): per workgroup the fp32 node-feature rows and the pre-computed half of the
- * node MLP that cross the O(n^2) edge passes through L2 (61 KB), plus, for team > 1, the exchange rows and arrival words. */
+ * compute units per molecule (0 or 1: one): per workgroup the node features and the pre-computed half of the node MLP that
+ * cross the O(n^2) edge passes through L2 (94 KB), plus, for team > 1, the exchange buffers (116 KB per molecule) and arrival words. */
 size_t dl_workspace_bytes(int32_t B, int32_t team);
 
 /* DynamicsWithPockets.forward (src/egnn.py:470-552): radius graph rebuilt on the GPU every call
@@ -222,16 +223,24 @@ typedef struct dl_chain_args {
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);
 
-/* Teams: a batch smaller than the chip leaves compute units idle when every molecule sits on one of them (the reference's
- * default sampling batch is 64, generate.py:145).  With team = 2, 4 or 8 that many workgroups share a molecule: each keeps the
- * whole molecule in LDS and repeats the per-atom phases, the O(n^2) pair loop is split by receiving atom and the message
- * sums are exchanged once per pass through the workspace (release / acquire hand-off inside the launch, placement-independent).
+/* Teams.  A batch smaller than the chip leaves compute units idle when every molecule sits on one of them (the reference's
+ * default sampling batch is 64, generate.py:145), and a molecule of more than dl_max_atoms() atoms does not fit one compute
+ * unit's LDS at all.  With team = 2, 4 or 8 that many workgroups share a molecule: its atoms are dealt round-robin, a member
+ * keeps the state of its own atoms only and runs the per-atom phases (node MLP, projections, sampler algebra) for them alone;
+ * its O(n^2) pair loops take its own atoms as receivers and every atom as sender, for which the members exchange the sender
+ * rows and coordinates of their atoms once per pass through the workspace (release / acquire hand-off inside the launch,
+ * placement-independent).  A team takes molecules of up to dl_team_max_atoms(team) = 110 atoms.
  * All team * ceil(B / 8) * 8 workgroups must be resident at once: dl_team_max(B) is the largest team the current device
- * holds for a batch of B (1, 2, 4 or 8); a larger request returns DL_ERR_BAD_ARG.  Results agree with team = 1 to fp32
- * rounding (the order in which an atom's messages are summed depends on the team size) and are bitwise repeatable for a
- * given team size.  nan_flags bit 3: a team member did not show up within the spin limit (another kernel held its
- * compute unit for seconds); the sample is void. */
+ * holds for a batch of B (1, 2, 4 or 8), a larger request returns DL_ERR_BAD_ARG, and the launch is cooperative (the runtime
+ * rejects a grid the device cannot hold).  Results agree with team = 1 to fp32 rounding (the order in which an atom's
+ * messages are summed depends on the team size) and are bitwise repeatable for a given team size.
+ * nan_flags bit 3: the members of a team did not all show up within the spin limit (another kernel held compute units for
+ * seconds); every member gives up together, the sample is void and the caller re-runs the batch with team = 1 (or
+ * dl_egnn_forward_fc_large).  With team > 1 the entry points zero nan_flags (and set nan_step to -1) on `stream` themselves. */
 int32_t dl_team_max(int32_t B);
+int32_t dl_team_max_atoms(int32_t team);
+/* tests only: when on, member 1 of every team gives up at its first exchange (exercises the fail-together path above) */
+void dl_debug_team_fault(int32_t on);
 /* dl_egnn_forward_fc with a team per molecule (team = 1: identical to dl_egnn_forward_fc) */
 int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,

@@ -78,8 +78,13 @@ def test_unsupported_combinations_raise():
     with pytest.raises(NotImplementedError):
         DynamicsWithPockets(n_dims=3, in_node_nf=9, context_node_nf=2, hidden_nf=128, n_layers=1, attention=True,
                             graph_type='FC-10A-4A')
-    # a molecule beyond the LDS-resident limit leaves the kernels that carry the options: refused, not silently wrong
-    dyn, _, _ = make(9, 1, 1, 230, dict(tanh=True), 'f16x3', 1.0)
-    inp, z, t = P.ragged_inputs([60], [5], 9, seed=231)
-    with pytest.raises(Exception):
+    # 56..110 atoms: a team of compute units per molecule, the same kernels, the options included
+    dyn, sd, cfg = make(9, 1, 1, 230, dict(tanh=True, attention=True, aggregation_method='mean'), 'f16x3', 1.0)
+    inp, z, t = P.ragged_inputs([60, 20], [5, 4], 9, seed=231)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    ev, eh = P.report('flags on a 60-atom molecule (team)', P.run_hip_forward(dyn, inp, z, t), ref, z)
+    assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+    # beyond that a molecule leaves the kernels that carry the options: refused before anything is launched, not silently wrong
+    inp, z, t = P.ragged_inputs([120, 20], [5, 4], 9, seed=232)
+    with pytest.raises(NotImplementedError):
         P.run_hip_forward(dyn, inp, z, t)

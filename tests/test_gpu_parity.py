@@ -246,10 +246,11 @@ def test_nan_raises_found_nan_exception_with_index_sets():
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
-@pytest.mark.parametrize('sizes,linkers', [([56, 10], [5, 2]), ([70, 33, 64], [9, 4, 12])])
+@pytest.mark.parametrize('sizes,linkers', [([116, 10], [5, 2]), ([130, 33, 120], [9, 4, 12])])
 def test_molecules_beyond_the_lds_limit_run_on_the_hbm_resident_kernels(sizes, linkers, precision):
-    """More than dl_max_atoms() atoms: Dynamics.forward switches to dl_egnn_forward_fc_large (the pocket path's
-    per-pass kernels on the dense masked edge list, self loops weighted -2 like the int8 mask says) - same numbers."""
+    """More than dl_team_max_atoms() = 110 atoms (round 3: 56..110 run fused on a team of compute units, tests/test_gpu_team.py):
+    Dynamics.forward switches to dl_egnn_forward_fc_large (the pocket path's per-pass kernels on the dense masked edge
+    list, self loops weighted -2 like the int8 mask says) - same numbers."""
     nf, L = 9, 2
     dyn, sd, cfg = make_dynamics(nf, 1, L, seed=14, precision=precision)
     inp, z, t = ragged_inputs(sizes, linkers, nf, seed=11)
@@ -263,7 +264,7 @@ def test_molecules_beyond_the_lds_limit_run_on_the_hbm_resident_kernels(sizes, l
     assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
     assert torch.equal(out, run_hip_forward(dyn, inp, z, t)), 'bitwise repeatable'
     # the same molecules that DO fit give the same answer on either path (first 10-atom molecule of the small case)
-    if sizes == [56, 10]:
+    if sizes == [116, 10]:
         small, zs, ts = ragged_inputs([10, 12], [2, 3], nf, seed=12)
         a = run_hip_forward(dyn, small, zs, ts)
         d = dev()
@@ -272,12 +273,14 @@ def test_molecules_beyond_the_lds_limit_run_on_the_hbm_resident_kernels(sizes, l
         assert rel_l2(b.cpu(), a) <= 2e-6
 
 
-@pytest.mark.parametrize('sizes,linkers', [([58, 12], [6, 3]),                       # mixed: one molecule beyond the limit
-                                           ([20, 70, 35, 60, 12, 56], [4, 9, 5, 8, 3, 6]),   # mixed, interleaved
-                                           ([58, 61], [6, 7])])                     # every molecule beyond the limit
+@pytest.mark.parametrize('sizes,linkers', [([118, 12], [6, 3]),                      # mixed: one molecule beyond every fused path
+                                           ([20, 70, 35, 120, 12, 56], [4, 9, 5, 8, 3, 6]),  # all three size classes, interleaved
+                                           ([58, 61], [6, 7]),                      # every molecule needs a team
+                                           ([118, 121], [6, 7])])                   # every molecule beyond the fused paths
 def test_chain_with_large_molecules_splits_the_batch(sizes, linkers):
-    """Molecules with more than dl_max_atoms() atoms take the HBM-resident kernels and the host-driven loop, the rest of
-    the batch the fused launch; noise rows and per-step scalars are those of the whole batch: the reference's numbers."""
+    """Molecules of up to dl_max_atoms() = 55 atoms take the fused chain on one compute unit (or a team) each, up to
+    dl_team_max_atoms() = 110 the fused chain on a team of at least two, bigger ones the HBM-resident kernels and the
+    host-driven loop; noise rows and per-step scalars are those of the whole batch: the reference's numbers."""
     from difflinker_amd import EDM
     nf, T, keep = 8, 6, 2
     dyn, sd, cfg = make_dynamics(nf, 1, 1, seed=33)
@@ -335,9 +338,11 @@ def test_sampler_step_kernel_matches_oracle_arithmetic():
 
 
 # ---------------------------------------------------------------------------------------------------
-def chain_case(nf, n_layers, sizes, linkers, T, keep, seed, timesteps=500, precision=None, coord_gain=0.02):
+def chain_case(nf, n_layers, sizes, linkers, T, keep, seed, timesteps=500, precision=None, coord_gain=0.02, team=None):
     from difflinker_amd import EDM
     dyn, sd, cfg = make_dynamics(nf, 1, n_layers, seed=seed, precision=precision, coord_gain=coord_gain)
+    if team is not None:
+        dyn.team = team
     inp, _, _ = ragged_inputs(sizes, linkers, nf, seed=seed + 1)
     B, N = inp['x'].shape[:2]
     edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=timesteps, noise_schedule='polynomial_2',

@@ -13,7 +13,7 @@ import torch
 
 from helpers import rel_l2
 from oracle import edm_oracle, egnn_oracle
-from test_gpu_parity import (CHAIN_TOL, FWD_TOLS, check_chain, dev, make_dynamics, ragged_inputs, report, run_hip_forward)
+from test_gpu_parity import (CHAIN_TOL, FWD_TOLS, chain_case, check_chain, dev, make_dynamics, ragged_inputs, report, run_hip_forward)
 
 pytestmark = pytest.mark.gpu
 
@@ -128,3 +128,53 @@ def test_team_requests_the_device_cannot_hold_are_refused():
     dyn.team = 3
     with pytest.raises(ValueError):
         run_hip_forward(dyn, inp, z, t)
+
+
+def test_a_team_that_cannot_assemble_fails_together_and_the_call_is_rerun_without_teams():
+    """ADVICE round 2 / VERDICT item 4.  `dl_debug_team_fault` makes member 1 of every team give up at its first exchange, as a
+    member whose team-mates never became resident would after its spin limit: it publishes the poison arrival word, every
+    other member stops waiting too, ALL of them end with flag bit 3 (raw C ABI), and the Python drop-in re-runs the batch on
+    one compute unit per molecule - the caller sees the oracle's numbers and no exception."""
+    import ctypes
+    from difflinker_amd import _lib
+    lib = _lib.load()
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=31)
+    inp, z, t = ragged_inputs([20, 33, 9, 50], [4, 6, 2, 9], nf, seed=17)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    dyn.team = 4
+    lib.dl_debug_team_fault(1)
+    try:
+        prep = dyn.prepare(inp['node_mask'].to(dev()), inp['linker_mask'].to(dev()), inp['edge_mask'].to(dev()), inp['context'].to(dev()))
+        out, flags = dyn.launch(prep, t.to(dev()), z.to(dev()))
+        torch.cuda.synchronize()
+        assert all(int(f) & 8 for f in flags.cpu().tolist()), 'every molecule of a failed launch is flagged void'
+        ev, eh = report('team fault -> rerun on one compute unit', run_hip_forward(dyn, inp, z, t), ref, z)
+        assert ev <= FWD_TOLS['f16x3'] and eh <= FWD_TOLS['f16x3']
+        # the fused chain too (same draws in both runs: the bank is fixed before the first launch)
+        got, want, cinp = chain_case(nf=9, n_layers=2, sizes=[22, 35], linkers=[5, 7], T=20, keep=1, seed=33, team=2)
+        check_chain('chain, team fault -> rerun', got, want, cinp)
+    finally:
+        lib.dl_debug_team_fault(0)
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+@pytest.mark.parametrize('sizes,linkers', [([56, 10], [5, 2]), ([70, 33, 110, 64], [9, 4, 12, 11])])
+def test_molecules_of_56_to_110_atoms_run_fused_on_teams(sizes, linkers, precision):
+    """a molecule beyond one compute unit's LDS takes a team of at least two (each member holds its own
+    atoms' state and every atom's sender row), no host-driven loop: forward and chain against the oracle."""
+    from difflinker_amd import _lib
+    nf = 9
+    assert _lib.load().dl_team_max_atoms(2) >= 110 and _lib.load().dl_team_max_atoms(1) == _lib.load().dl_max_atoms() == 55
+    dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=41, precision=precision)
+    inp, z, t = ragged_inputs(sizes, linkers, nf, seed=sum(sizes))
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    for team in ('auto', 2):
+        dyn.team = team
+        prep = dyn.prepare(inp['node_mask'].to(dev()), inp['linker_mask'].to(dev()), inp['edge_mask'].to(dev()), inp['context'].to(dev()))
+        kinds = [(p_['large'], p_['team']) for p_ in prep.get('split', [prep])]
+        assert not any(large for large, _ in kinds), 'no molecule of this batch needs the HBM-resident kernels'
+        ev, eh = report(f'fwd sizes={sizes} team={team} {precision}', run_hip_forward(dyn, inp, z, t), ref, z)
+        assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
+    got, want, cinp = chain_case(nf=9, n_layers=2, sizes=sizes, linkers=linkers, T=30, keep=3, seed=43, precision=precision)
+    check_chain(f'chain sizes={sizes} {precision}', got, want, cinp)
