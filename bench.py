@@ -8,13 +8,19 @@ final decode = 501 EGNN forwards, per GPU the workload of BASELINE config C2 (GE
 B = 256 molecules padded to N = 50, n_b ~ U{35..50}).  Weak scaling: every rank samples its own 256
 molecules (global batch 256*N, config C3 at N = 8); no data-path collective, one all-gather of the
 final frame (RCCL over xGMI) inside the timed region.  Inputs are resident in HBM before the timed
-region; the noise draws (reference ``torch.randn`` call sequence) are part of the step.
+region; the noise is drawn inside the kernel (counter-based Philox keyed by the global molecule index, the
+same source at every --gpus; --noise torch = the reference's ``torch.randn`` call sequence, a secondary line).
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     — fp32-MFMA roofline of the dominant kernel (``sample_chain_fc_kernel``): algorithmic
-                 FLOPs (SURVEY 8d F_min x 501 forwards) / live HIP-event duration of the launch
+  roofline     — MFMA roofline of the dominant kernel (``sample_chain_fc_kernel``): the FLOPs the kernel
+                 executes x 501 forwards / live HIP-event duration of the launch (the reference algorithm's
+                 count, SURVEY 8d F_min, is the `algorithmic` side entry)
   cpu_baseline — the oracle (PyTorch-CPU port of the reference path) timed on this box's host cores
                  on a bounded sample (2 forwards of the same batch, extrapolated x501).
+  secondary    — driver-timed companions: exact-fp32 mode, torch noise, C4, C5 (one GPU's shard), molecules of
+                 60..80 atoms, other batch sizes.
+  --config C5 / C4 / C1 / C2L select another workload as the headline; --backend gloo runs --gpus N as N ranks
+  on ONE GPU (functional check of the sharded branch on a single-GPU box).
 """
 import argparse
 import json
@@ -39,12 +45,17 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4'])
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4', 'C5', 'C2L'])
     ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
     ap.add_argument('--T', type=int, default=None, help='reverse steps (default: the config\'s, 500 for C2)')
     ap.add_argument('--uniform-size', action='store_true', help='unpadded variant: every molecule has N atoms')
-    ap.add_argument('--noise', default='torch', choices=['torch', 'philox'],
-                    help="'torch': the reference's torch.randn stream (default); 'philox': draws generated inside the kernel")
+    ap.add_argument('--noise', default='philox', choices=['torch', 'philox'],
+                    help="'philox' (default, every --gpus): counter-based draws generated inside the kernel, keyed by the global "
+                         "molecule index - what a batch sharded over GPUs needs; 'torch': the reference's torch.randn call "
+                         "sequence (1004 launches per chain on the host's stream; N = 1 only, reported as a secondary line)")
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="torch.distributed backend of --gpus > 1: 'nccl' = RCCL over xGMI (default); 'gloo' lets several ranks "
+                         "share ONE GPU (functional check of the sharded path on a single-GPU box; RCCL refuses that)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-forwards', type=int, default=2)
     ap.add_argument('--no-secondary', action='store_true',
@@ -59,7 +70,7 @@ def build_model(cfg, device):
     cls = Dynamics if cfg['graph_type'] == 'FC' else DynamicsWithPockets
     dyn = cls(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128,
               n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm', graph_type=cfg['graph_type'])
-    edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+    edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=cfg.get('timesteps', 500), noise_schedule='polynomial_2',
               noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
     edm.T = cfg['T']
     if cfg.get('precision'):
@@ -151,14 +162,14 @@ def secondary_measurements(device, a):
     from difflinker_amd import synthetic
     out = []
 
-    def run(tag, config, batch, precision, note, team='auto'):
+    def run(tag, config, batch, precision, note, team='auto', noise=None):
         data, cfg = synthetic.make_batch(config, seed=1000, batch=batch)
         cfg['precision'] = precision
         pockets = cfg['graph_type'] != 'FC'
         inp_cpu = synthetic.sampler_inputs(data, pockets=pockets)
         inp = {k: v.to(device) for k, v in inp_cpu.items()}
         edm = build_model(cfg, device)
-        edm.noise_source = a.noise
+        edm.noise_source = noise or a.noise
         edm.dynamics.team = team
         if hasattr(edm, 'last_kernel_events'):
             del edm.last_kernel_events
@@ -171,20 +182,23 @@ def secondary_measurements(device, a):
         peak = FP32_MFMA_PEAK_TFLOPS if precision == 'fp32' else F16_MFMA_PEAK_TFLOPS / 3.0
         t_k = (kms * 1e-3) if kms is not None else dt
         B = inp['x'].shape[0]
-        out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}; {note}',
-                    'compute_units_per_molecule': None if (pockets or config == 'C2L') else edm.dynamics.team_for(B), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
+        out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}, noise={edm.noise_source}; {note}',
+                    'compute_units_per_molecule': None if pockets else (2 if config == 'C2L' else edm.dynamics.team_for(B)), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
                     'roofline_frac': flops / t_k / 1e12 / peak, 'roofline_peak_tflops': peak,
                     'achieved_tflops': flops / t_k / 1e12})
 
     run('c2_fp32_mode', 'C2', None, 'fp32', 'exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), same batch as the headline')
-    run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph rebuilt every forward')
-    run('c2_large_molecules', 'C2L', None, 'f16x3', '60..80 atoms per molecule: beyond the LDS-resident limit (55), HBM-resident per-pass '
-        'kernels on the dense masked edge list (dl_egnn_forward_fc_large), chain driven from the host')
+    run('c2_torch_noise', 'C2', None, 'f16x3', "the headline batch with the reference's torch.randn call sequence as the noise source "
+        '(2 x 502 randn launches per chain on the stream, a 308 MB bank in HBM) instead of the in-kernel draws', noise='torch')
+    run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph')
+    run('c5_shard', 'C5', None, 'f16x3', 'BASELINE config 5, one GPU\'s shard: the C4 molecules, batch 64, EDM built with timesteps = 1000, T = 1000')
+    run('c2_large_molecules', 'C2L', None, 'f16x3', '60..80 atoms per molecule: beyond one compute unit\'s LDS (55), fused chain on teams of two '
+        'compute units per molecule (each holds its own atoms\' state and every atom\'s sender row); round 2: HBM-resident kernels, host loop')
     run('c2_batch_64_one_cu_each', 'C2', 64, 'f16x3', 'the reference\'s default sampling batch (generate.py:145), one compute unit per '
         'molecule: a quarter of the chip', team=1)
     for b in (64, 128, 257, 512):
         run(f'c2_batch_{b}', 'C2', b, 'f16x3', 'Dynamics.team = auto: 4 / 2 compute units per molecule while the batch leaves the chip '
-            'room (pair loop split by receiving atom, message sums exchanged through HBM once per pass), else one, biggest first')
+            'room (atoms dealt round-robin, per-atom phases split, sender rows exchanged through HBM once per pass), else one, biggest first')
     return out
 
 
@@ -195,11 +209,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus or (a.gpus == 1 and world == 1), f'--gpus {a.gpus} but WORLD_SIZE={world}'
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank if a.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        if a.backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+        else:                                              # several ranks on one GPU (functional check)
+            dist.init_process_group('gloo', rank=rank, world_size=world)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -226,7 +243,8 @@ def main():
     lo, hi = shard_bounds(Bg, rank, world)
     B = hi - lo
     edm = build_model(cfg, device)
-    edm.noise_source = a.noise if world == 1 else 'philox'
+    assert world == 1 or a.noise == 'philox', 'a batch sharded over ranks needs the counter-based noise (--noise philox)'
+    edm.noise_source = a.noise
     edm.profile_events = True
     shard_cpu = {k: (v[lo:hi] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == Bg else v) for k, v in inp_cpu.items()}
     pairs, nodes = synthetic.pair_and_node_counts({'atom_mask': data['atom_mask'][lo:hi]})
@@ -282,22 +300,22 @@ def main():
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
         # fabric-side bytes per launch: NOT measured in this run (rocprofv3 --pmc passes cannot run inside the timed
-        # process) but taken from the committed counter passes of the same launch (profiles/r02/pmc_chain_kernel_T500.json,
+        # process) but taken from the committed counter passes of the same launch (profiles/r03/pmc_chain_kernel_T500.json,
         # collected by scripts/profile_gpu.sh on this command line; FETCH_SIZE doubled for gfx950) - labelled as such
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02', 'pmc_chain_kernel_T500.json')
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03', 'pmc_chain_kernel_T500.json')
         if not pockets and precision == 'f16x3' and a.config == 'C2' and not a.uniform_size and os.path.exists(pmc_path):
             d_ = json.load(open(pmc_path))['_derived']
             per_fwd = (d_['hbm_fetch_bytes_per_launch_x2_corrected'] + d_['hbm_write_bytes_per_launch']) / float(d_['forwards_per_launch'])
             traffic = per_fwd * (cfg['T'] + 1) * (B / 256.0)
-            traffic_note = 'from_profile: FETCH_SIZE x2 + WRITE_SIZE of profiles/r02/pmc_chain_kernel_T500.json (the same launch, ' \
+            traffic_note = 'from_profile: FETCH_SIZE x2 + WRITE_SIZE of profiles/r03/pmc_chain_kernel_T500.json (the same launch, ' \
                            'separate rocprofv3 --pmc passes); fabric-side, Infinity-Cache hits included (scratch + weight ' \
                            'streaming); algorithmic HBM bytes are ~2 MB per forward'
         out = {
             'metric': 'molecules/sec (500-step sample_chain)', 'value': Bg * a.steps / elapsed,
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic', 'noise': a.noise,
+            'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic', 'noise': edm.noise_source,
             'config': {'workload': f'{a.config}: {"GEOM geom_difflinker" if not pockets else "pockets_difflinker_full_no_anchors_fc (FC-10A-4A radius graph)"} hparams (egnn_dynamics, hidden 128, '
                                    f'{cfg["n_layers"]} blocks), batch={B} molecules/GPU padded to N={N} '
                                    f'(n_b {"= N" if a.uniform_size else ("~ U{35..50}" if not pockets else "30 fragment + 250 pocket + 6..12 linker atoms")}), T={cfg["T"]} reverse steps '
@@ -305,16 +323,22 @@ def main():
                                    f'fragment graphs',
                        'global_batch': Bg, 'molecules_per_gpu': B, 'n_nodes': N, 'T': cfg['T'], 'parallelism': f'batch-shard x{world}' + ('' if world == 1 else ' (distributed.sample_chain_sharded: contiguous shards, in-kernel Philox noise keyed by the global molecule index, one RCCL all-gather of the final frame)'),
                        'real_pairs_per_forward': pairs, 'coordinate_pass_pairs_per_forward': pairs_coord, 'real_atoms': nodes},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
-                         'frac_of_fp32_vector_peak': achieved / FP32_MFMA_PEAK_TFLOPS,
+            # primary figures: the work the kernels EXECUTE: the coordinate head runs for receiving atoms
+            # inside the linker mask only - the reference multiplies every other atom's sum by zero (egnn.py:113-116) - so
+            # the reference algorithm's flop count (SURVEY 8d F_min: every pair in all three edge models) overstates how
+            # busy the hardware is; it stays as the `algorithmic` side entry
+            'roofline': {'bound': 'mfma', 'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': executed / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
+                         'frac_of_fp32_vector_peak': executed / FP32_MFMA_PEAK_TFLOPS,
                          'kernel': 'sample_chain_fc_kernel' if not pockets else 'all kernels of the chain (pk_edge_kernel dominates)', 'kernel_ms': k_avg_ms,
-                         'flops_per_launch': flops_fwd * (cfg['T'] + 1),
-                         'executed': {'achieved': executed, 'frac': executed / peak, 'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1),
-                                      'note': 'achieved / frac above count the reference algorithm (SURVEY 8d F_min: every pair in all three '
-                                              'edge models of a block); the kernels skip the coordinate head for receiving atoms outside the '
-                                              'linker mask, whose sum the reference multiplies by zero (egnn.py:113-116) - this entry counts '
-                                              'only the pairs really evaluated (' + str(pairs_coord) + ' of ' + str(pairs) + ' per coordinate pass)'}},
+                         'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1),
+                         'counts': 'executed work: GCL edge models on every pair, coordinate edge model on the ' + str(pairs_coord) + ' of '
+                                   + str(pairs) + ' pairs per pass whose receiving atom is inside the linker mask, per-atom GEMMs',
+                         'algorithmic': {'achieved': achieved, 'frac': achieved / peak, 'flops_per_launch': flops_fwd * (cfg['T'] + 1),
+                                         'note': 'SURVEY 8d F_min x (T + 1): the reference algorithm, every pair in all three edge models '
+                                                 'of a block / the same kernel time'},
+                         # kept for continuity with rounds 1-2, whose lines carried the executed figures under this key
+                         'executed': {'achieved': executed, 'frac': executed / peak, 'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1)}},
             'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
                           'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '

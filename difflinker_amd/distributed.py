@@ -53,9 +53,15 @@ def all_gather_frames(local_chain, batch_size, group=None):
     assert b_r == sizes[rank][1] - sizes[rank][0]
     send = local_chain.new_zeros((k, bmax, n, d))
     send[:, :b_r] = local_chain
+    # RCCL ('nccl') gathers device tensors in place; gloo (several ranks on ONE GPU: functional checks on a single-GPU box)
+    # has no device all-gather - the frames take the detour through host memory there
+    via_host = send.is_cuda and dist.get_backend(group) == 'gloo'
+    if via_host:
+        send = send.cpu()
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send.contiguous(), group=group)
-    return torch.cat([recv[r][:, :sizes[r][1] - sizes[r][0]] for r in range(world)], dim=1)
+    out = torch.cat([recv[r][:, :sizes[r][1] - sizes[r][0]] for r in range(world)], dim=1)
+    return out.to(local_chain.device) if via_host else out
 
 
 def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=None, gather=True):

@@ -20,8 +20,12 @@ CONFIGS = {
     'C2': dict(nf=9, ctx=1, n_layers=6, batch=256, n_max=50, n_lo=35, linker=(3, 12), T=500, graph_type='FC'),
     'C4': dict(nf=9, ctx=2, n_layers=6, batch=64, n_frag=30, n_pocket=250, linker=(6, 12), T=500,
                graph_type='FC-10A-4A'),
-    # not a BASELINE configuration: GEOM hparams on molecules beyond the LDS-resident limit of 55 atoms (bench.py's
-    # secondary line for the HBM-resident fully-connected path)
+    # BASELINE config 5, per-GPU shard: the C4 molecules, 64 per GPU (512 over 8), an EDM built with timesteps = 1000 and
+    # sampled over all of them (no duplicate-gamma steps)
+    'C5': dict(nf=9, ctx=2, n_layers=6, batch=64, n_frag=30, n_pocket=250, linker=(6, 12), T=1000, timesteps=1000,
+               graph_type='FC-10A-4A'),
+    # not a BASELINE configuration: GEOM hparams on molecules of 60..80 atoms - beyond one compute unit's LDS (55 atoms):
+    # round 3 runs them fused on teams of two compute units, round 2 on the HBM-resident kernels under a host-driven loop
     'C2L': dict(nf=9, ctx=1, n_layers=6, batch=64, n_max=80, n_lo=60, linker=(3, 12), T=500, graph_type='FC'),
 }
 

@@ -101,6 +101,9 @@ def report(tag, out, ref, xin=None):
     eh = rel_l2(out[..., 3:], ref[..., 3:])
     raw = rel_l2(out[..., :3], ref[..., :3])
     print(f'[{tag}] rel-L2 vel {ev:.3e} (raw {raw:.3e}) h {eh:.3e} | max-abs {max_abs(out, ref):.3e}')
+    # the north-star bar holds for the RAW velocity error too, floor and all (the floor-corrected figure
+    # printed 0 everywhere); where the update is not tiny - test_forward_velocity_with_a_live_coordinate_head - it is tight
+    assert raw <= 1e-4, f'{tag}: raw velocity rel-L2 {raw:.3e} above the 1e-4 bar'
     return ev, eh
 
 
@@ -129,6 +132,25 @@ def test_forward_vs_oracle(sizes, linkers, n_layers, precision):
     nm = inp['node_mask'].float()
     assert float((out * (1 - nm)).abs().max()) == 0.0, 'padded rows must be exactly zero'
     assert ev <= FWD_TOLS[precision] and eh <= FWD_TOLS[precision]
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+def test_forward_velocity_with_a_live_coordinate_head(precision):
+    """One forward with a coordinate head at xavier gain 1.0 (a thousand times the reference's init): the velocity is of the
+    order of the coordinates themselves, the ulp(|x|) floor of `report` is irrelevant, and the RAW velocity error must meet
+    the forward tolerance - a wrong coordinate update could not hide behind the floor."""
+    nf = 9
+    dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=107, coord_gain=1.0, precision=precision)
+    inp, z, t = ragged_inputs([50, 35, 44, 12], [8, 3, 12, 4], nf, seed=108)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    out = run_hip_forward(dyn, inp, z, t)
+    report(f'fwd, coordinate head gain 1.0, {precision}', out, ref, z)
+    lm = inp['linker_mask']
+    vel_scale = float((ref[..., :3] * lm).norm() / (z[..., :3] * lm).norm())
+    raw = rel_l2(out[..., :3], ref[..., :3])
+    print(f'   |velocity| / |x| over the linker atoms: {vel_scale:.3f}; raw velocity rel-L2 {raw:.3e}')
+    assert vel_scale > 1e-2, 'the update must dominate the rounding floor for this test to mean anything'
+    assert raw <= FWD_TOLS[precision]
 
 
 def test_forward_vs_reference_golden(golden_dir):

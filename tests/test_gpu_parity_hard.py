@@ -101,6 +101,55 @@ def count_threshold_sensitive_pairs(x, node_mask):
     return flips
 
 
+def pairs_near_a_cutoff(x, node_mask, eps):
+    """(pair, frame) count of real-atom pairs whose distance is within `eps` of the 4 A or 10 A cut-off."""
+    hits = 0
+    for b in range(x.shape[0]):
+        real = node_mask[b].reshape(-1) != 0
+        xb = x[b][real].double()
+        d = (xb[:, None, :] - xb[None, :, :]).pow(2).sum(-1).sqrt()
+        for thr in (4.0, 10.0):
+            hits += int(((d - thr).abs() < eps).sum())
+    return hits
+
+
+def test_pocket_chain_at_c4_size_with_the_graph_pinned():
+    """A T = 50 chain at the C4 geometry and depth (30 fragment + 250 pocket + 6..12 linker atoms, N = 291, FC-10A-4A, 6 blocks,
+    B = 2) against the oracle, every frame kept.  The radius graph is rebuilt by different code on the two sides (torch.cdist
+    on the host, direct differences on the GPU), so the test first PROVES the graphs cannot differ: along the oracle's
+    trajectory no pair of atoms comes within 1e-4 A of a cut-off (asserted: 0 of ~4 M pair-frames for this seed), while the two
+    implementations' coordinates agree to ~1e-6 A wherever an atom is near anything - every edge set of the chain is the same
+    on both sides, and the frame-by-frame parity below is a statement about the arithmetic alone."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    from difflinker_amd import EDM
+    nf, T, seed = 9, 50, 151
+    dyn, sd, cfg = P.make_pocket_dynamics(nf, 6, seed=seed)
+    inp, _, _ = P.pocket_inputs(batch=2, n_frag=30, n_pocket=250, linker=(6, 12), nf=nf, seed=seed + 2)
+    B, N = inp['x'].shape[:2]
+    assert N >= 286
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+              loss_type='l2', norm_values=[1, 4, 10]).to(P.dev())
+    edm.T = T
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=seed + 4)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                            inp['edge_mask'], inp['context'], bank, keep_frames=T)
+    assert torch.isfinite(want).all()
+    near = sum(pairs_near_a_cutoff(want[k][..., :3], inp['node_mask'], 1e-4) for k in range(T))
+    flips = sum(count_threshold_sensitive_pairs(want[k][..., :3], inp['node_mask']) for k in range(T))
+    assert near == 0 and flips == 0, f'{near} pair-frames within 1e-4 A of a cut-off, {flips} formula-sensitive: pick another seed'
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
+                           g['context'], keep_frames=T, noise_bank=bank.stacked()).cpu()
+    P.check_chain(f'pocket chain at C4 size, T={T}, graph pinned', got, want, inp)
+    # wherever an atom sits near anything the two sides agree far below the 1e-4 A margin the graph proof needs
+    close = (want[..., :3].abs().amax(-1) < 50.0) & (inp['node_mask'].squeeze(-1) != 0)[None]
+    worst = float(((got[..., :3] - want[..., :3]).norm(dim=-1) * close).max())
+    print(f'   largest coordinate difference among atoms within 50 A of the origin, any frame: {worst:.2e} A')
+    assert worst < 2e-5
+
+
 def test_pocket_chain_T50_reports_edge_flips():
     """A 50-step pocket chain (linker atoms move across the 10 A cut-off of ~100 pocket atoms) against the oracle, every
     frame kept; pairs whose graph membership depends on the distance formula are counted along the oracle's trajectory."""
@@ -160,6 +209,62 @@ def test_chain_T500_with_a_live_coordinate_head():
     got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
                            g['context'], keep_frames=5, noise_bank=bank.stacked()).cpu()
     P.check_chain('chain T=500, live coordinate head', got, want, inp)
+
+
+def test_chain_T500_with_a_live_coordinate_head_geom_sized():
+    """The same at the benchmark's molecule size (the live-head chain stopped at 30 atoms): four molecules
+    of 41..50 atoms, 6 blocks, T = 500, coordinate head at xavier gain 0.02 - the oracle stays finite (largest coordinate
+    ~ 760 A) - on one compute unit per molecule and on teams."""
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    from difflinker_amd import EDM, synthetic
+    from difflinker_amd.datasets import collate
+    nf, L, T, gain = 9, 6, 500, 0.02
+    sizes, linkers = [50, 44, 41, 47], [8, 6, 5, 9]
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=96, coord_gain=gain)
+    inp = synthetic.sampler_inputs(collate(ragged_fc_molecules(sizes, linkers, nf, seed=93)))
+    B, N = inp['x'].shape[:2]
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+              loss_type='l2', norm_values=[1, 4, 10]).to(P.dev())
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=94)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'],
+                            inp['edge_mask'], inp['context'], bank, keep_frames=1)
+    assert torch.isfinite(want).all()
+    lm = inp['linker_mask']
+    moved = float(((want[0][..., :3] - inp['x']) * lm).norm(dim=-1).max())
+    print(f'[T=500 live head, 41..50 atoms] largest linker displacement {moved:.1f} A')
+    assert moved > 10.0
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    for team in (1, 'auto'):
+        dyn.team = team
+        got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'],
+                               g['context'], keep_frames=1, noise_bank=bank.stacked()).cpu()
+        P.check_chain(f'chain T=500, live coordinate head, 41..50 atoms, team={team}', got, want, inp)
+
+
+def test_headline_arithmetic_against_the_exact_mode_at_full_size():
+    """The benchmark's own launch - config C2, B = 256, T = 500, in-kernel noise - once in the default f16x3 arithmetic and once
+    in the exact-fp32 MFMA mode: the two final samples agree to 1e-5 on the linker coordinates and in every atom type, which
+    ties the headline's arithmetic to the exact one at full size (the oracle cannot follow there: an hour per chain)."""
+    from difflinker_amd import Dynamics, EDM, synthetic
+    data, cfg = synthetic.make_batch('C2', seed=1000)
+    inp = {k: v.to(P.dev()) for k, v in synthetic.sampler_inputs(data).items()}
+    chains = {}
+    for precision in ('f16x3', 'fp32'):
+        torch.manual_seed(0)
+        dyn = Dynamics(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128, n_layers=cfg['n_layers'],
+                       norm_constant=1e-6, normalization='batch_norm')
+        dyn.precision = precision
+        edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+                  loss_type='l2', norm_values=[1, 4, 10]).to(P.dev())
+        edm.noise_source, edm.noise_seed = 'philox', 5
+        chains[precision] = edm.sample_chain(keep_frames=1, **inp).cpu()
+    lm = inp['linker_mask'].cpu()
+    a, b = chains['f16x3'][0], chains['fp32'][0]
+    ex = rel_l2(a[..., :3] * lm, b[..., :3] * lm)
+    mism = int((a[..., 3:] != b[..., 3:]).any(-1).sum())
+    print(f'[C2 B=256 T=500, f16x3 vs fp32 mode] final linker-x rel-L2 {ex:.3e}, atom-type mismatches {mism}')
+    assert torch.isfinite(a).all() and ex <= 1e-5 and mism == 0
 
 
 def test_split_fp16_is_fp32_class_against_the_fp64_oracle():
