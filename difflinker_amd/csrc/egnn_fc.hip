@@ -152,9 +152,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned b) {
     const auto r32 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
     return max((unsigned)r32[0], (unsigned)r32[1]);
 }
+// LDS atomic maximum as the bare instruction: behind atomicMax() the compiler puts s_waitcnt vmcnt(0) - i.e. a wait for every
+// fragment prefetch and LDS-DMA in flight (1-2 us in the per-atom phases) - although an LDS maximum orders nothing against them
+__device__ __forceinline__ void lds_max_u32(unsigned* slot, unsigned val) {
+    const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)slot;
+    asm volatile("ds_max_u32 %0, %1" :: "v"(addr), "v"(val) : "memory");
+}
 __device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
     const unsigned b = wave_max_u32(__float_as_uint(val));
-    if (lane == 0) atomicMax(slot, b);
+    if (lane == 0) lds_max_u32(slot, b);
 }
 
 // Workgroup barrier for LDS hand-offs that does NOT drain the vector-memory counter (unlike __syncthreads(), whose
@@ -1019,9 +1025,9 @@ __device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, c
         if (tid < S) { const u32x4 hdr = __builtin_amdgcn_raw_buffer_load_b128(rows, hbase + tid * 16, 0, 16); hm = hdr.x; }
         const unsigned b = wave_max_u32(__float_as_uint(n2)), hb = wave_max_u32(hm);
         if ((tid & 63) == 0) {
-            atomicMax(&v.fmax[nxt], b);
-            if (first) atomicMax(&v.fmax[FM_X02], b);
-            if (tid == 0) atomicMax(&v.fmax[FM_HG], hb);
+            lds_max_u32(&v.fmax[nxt], b);
+            if (first) lds_max_u32(&v.fmax[FM_X02], b);
+            if (tid == 0) lds_max_u32(&v.fmax[FM_HG], hb);
         }
     }
     lds_barrier();
@@ -1170,8 +1176,12 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     if (active) {
         AReg a;
         load_a<PREC>(a, v.B, arow, hh);
+        // the residual (+ bias) is taken into registers HERE: once the prefetches below are in flight a wait for it would be a
+        // wait for all of them (on the path of the last pass, which issues none, the compiler's one s_waitcnt has to be 0)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) acc2[reg] = (PREC == 0) ? hold[reg] + b4 : 0.0f;
+        for (int reg = 0; reg < 16; ++reg) { hold[reg] += b4; acc2[reg] = (PREC == 0) ? hold[reg] : 0.0f; }
+        asm volatile("" : "+v"(hold[0]), "+v"(hold[1]), "+v"(hold[2]), "+v"(hold[3]), "+v"(hold[4]), "+v"(hold[5]), "+v"(hold[6]), "+v"(hold[7]));
+        asm volatile("" : "+v"(hold[8]), "+v"(hold[9]), "+v"(hold[10]), "+v"(hold[11]), "+v"(hold[12]), "+v"(hold[13]), "+v"(hold[14]), "+v"(hold[15]));
         prof_event(pf, w, lane, 106);
         tile_mma<PREC>(acc2, a, b4f);
         prof_event(pf, w, lane, 107);
@@ -1179,8 +1189,12 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     __builtin_amdgcn_sched_barrier(0);
     // behind layer 2's matrix instructions (their operands have been read): the fragments the next pass opens with, then the
     // next pass's W2' image - requested in the order of use, landing under the epilogue and the barrier
+#ifndef DL_V_PRE_AFTER
     load_pre2(pw, nx, w, lane);
+#endif
+#if !defined(DL_V_DMA_AFTER) && !defined(DL_V_PRE_AFTER)
     stage_next(v, nx, w, tid);
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
         floatx16& acc = acc2;
@@ -1189,7 +1203,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
-            const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hold[reg] + b4);
+            const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hold[reg]);
             put_elem<PREC>(row < nown ? v.C + row * LDH : v.dummy, 32 * nt + c, hv, s_hn);
             hs[HS_HT + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hv;
             hm = fmaxf(hm, row < nown ? fabsf(hv) : 0.0f);
@@ -1200,6 +1214,12 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         if (PREC == 1) v.fmax[FS_HS] = __float_as_uint(s_hn);
         v.misc[CX_PAR] = par ^ 1;
     }
+#ifdef DL_V_PRE_AFTER
+    load_pre2(pw, nx, w, lane);
+#endif
+#if defined(DL_V_DMA_AFTER) || defined(DL_V_PRE_AFTER)
+    stage_next(v, nx, w, tid);
+#endif
     prof_event(pf, w, lane, 16);
     lds_barrier();
     if constexpr (TEAM) {
@@ -1328,7 +1348,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
             n2 = x0 * x0 + x1 * x1 + x2 * x2;
         }
         const unsigned b = wave_max_u32(__float_as_uint(n2));
-        if (lane == 0) { atomicMax(&v.fmax[FM_X2], b); atomicMax(&v.fmax[FM_X02], b); }
+        if (lane == 0) { lds_max_u32(&v.fmax[FM_X2], b); lds_max_u32(&v.fmax[FM_X02], b); }
     }
     // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224) -> fp32 rows in v.B (and the HBM scratch)
     {
