@@ -130,7 +130,7 @@ def load():
     lib.dl_inpaint_step.restype = i32
     lib.dl_inpaint_step.argtypes = [i32, i32, i32] + [vp] * 10 + [DLInpaintCoef, vp, vp]
     lib.dl_philox_fill.restype = i32
-    lib.dl_philox_fill.argtypes = [ctypes.c_uint64, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.dl_philox_fill.argtypes = [ctypes.c_uint64, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.dl_size_model_num_tensors.restype = i32
     lib.dl_size_model_num_tensors.argtypes = [ctypes.POINTER(DLSizeConfig)]
     lib.dl_size_model_create.restype = i32

@@ -2354,8 +2354,8 @@ __global__ void __launch_bounds__(256) inpaint_step_kernel(int N, int nf, const 
     }
 }
 
-__global__ void philox_fill_kernel(unsigned long long seed, int mol_offset, int B, int N, int nf, int draw0, int n_draws,
-                                   float* noise_x, float* noise_h) {
+__global__ void philox_fill_kernel(unsigned long long seed, int mol_offset, const int* __restrict__ mol_index, int B, int N, int nf,
+                                   int draw0, int n_draws, float* noise_x, float* noise_h) {
     const int D = 3 + nf;
     const long long total = (long long)n_draws * B * N * D;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
@@ -2364,7 +2364,7 @@ __global__ void philox_fill_kernel(unsigned long long seed, int mol_offset, int 
         const int n = int(node % N);
         const int b = int((node / N) % B);
         const int k = int(node / ((long long)N * B));
-        const float val = philox_normal(seed, unsigned(mol_offset + b), unsigned(n), unsigned(draw0 + k), unsigned(d));
+        const float val = philox_normal(seed, unsigned(mol_offset + (mol_index ? mol_index[b] : b)), unsigned(n), unsigned(draw0 + k), unsigned(d));
         if (d < 3) noise_x[node * 3 + d] = val;
         else noise_h[node * nf + d - 3] = val;
     }
@@ -2383,14 +2383,14 @@ int32_t dl_inpaint_step(int32_t B, int32_t N, int32_t nf, const float* z_t, cons
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
 
-int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, int32_t B, int32_t N, int32_t nf, int32_t draw0,
+int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, const int32_t* mol_index, int32_t B, int32_t N, int32_t nf, int32_t draw0,
                        int32_t n_draws, float* noise_x, float* noise_h, void* stream) {
     if (!noise_x || !noise_h || B < 0 || N < 1 || nf < 1 || n_draws < 0 || draw0 < 0 || mol_offset < 0) return DL_ERR_BAD_ARG;
     const long long total = (long long)n_draws * B * N * (3 + nf);
     if (total == 0) return DL_OK;
     const int blocks = int(std::min<long long>((total + 255) / 256, 4096));
     hipLaunchKernelGGL(philox_fill_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       (unsigned long long)seed, mol_offset, B, N, nf, draw0, n_draws, noise_x, noise_h);
+                       (unsigned long long)seed, mol_offset, mol_index, B, N, nf, draw0, n_draws, noise_x, noise_h);
     return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
 }
 

@@ -34,12 +34,16 @@ struct PkDims {
     int graph_type;                      // 0: '4A', 1: 'FC-4A', 2: 'FC-10A-4A', 3: fully connected with an int8 edge mask
     const int8_t* emask;                 // graph_type 3: [B,N,N] mask values (0: no edge; the value weights the message)
     float norm_constant;
+    // optional hyper-parameters (round 3; src/egnn.py:42-43,52-54 attention, :104-105 tanh, :315-319 mean)
+    int attention, tanh, mean;
+    float coords_range, inv_norm;
 };
 
 // workspace carve-up (all offsets in bytes, 256-B aligned)
 struct PkWs {
     float *H, *P, *Q, *X, *X0, *partial, *partialx, *partialA, *partialxA, *pmax, *qmax, *wgt;
     int *flags, *ntile, *tile_off, *tile_row, *col, *total;   // ntile / tile_off / tile_row count QUADS (8 edge slots)
+    int* deg;                                                 // edges per receiving atom ('mean' divides by it, egnn.py:315-319)
     int* eq_tiles;                                            // tiles with a receiving atom the coordinate update keeps; count: total[1]
     size_t bytes;
 };
@@ -63,6 +67,7 @@ inline PkWs carve(void* base, int B, int N) {
     w.qmax = reinterpret_cast<float*>(take(V * 4));
     w.flags = reinterpret_cast<int*>(take(V * 4));
     w.ntile = reinterpret_cast<int*>(take(V * 4));
+    w.deg = reinterpret_cast<int*>(take(V * 4));
     w.tile_off = reinterpret_cast<int*>(take((V + 1) * 4));
     w.total = reinterpret_cast<int*>(take(256));
     w.tile_row = reinterpret_cast<int*>(take(QMAX * 4));
@@ -171,7 +176,7 @@ __global__ void pk_edges_kernel(PkDims d, PkWs w) {
     }
     const int nt = (count + 7) >> 3;                                                                // quads of this atom
     if (!FILL) {
-        if (lane == 0) w.ntile[v] = nt;
+        if (lane == 0) { w.ntile[v] = nt; w.deg[v] = count; }
     } else {
         for (int e = count + lane; e < nt * 8; e += 64) {                                           // padding
             w.col[size_t(base_tile) * 8 + e] = -1;
@@ -304,6 +309,12 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
                         av.x += pv.x; av.y += pv.y; av.z += pv.z; av.w += pv.w;
                     }
                 }
+                if (d.mean) {
+                    // 'mean': the row's edge count, masked edges included - the whole padded row on the reference's dense list
+                    // (graph_type 3), the atom's degree in a radius graph; an atom without edges divides by 1 (egnn.py:315-319)
+                    const float ms = 1.0f / float(d.graph_type == 3 ? d.N : max(w.deg[v], 1));
+                    av.x *= ms; av.y *= ms; av.z *= ms; av.w *= ms;
+                }
             }
         }
         *reinterpret_cast<float4*>(hL + r * LDT + 4 * q) = hv;
@@ -417,10 +428,13 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
 //    The run that opens the tile goes to partial[t] / partialx[t], a run that starts inside it - the first quads of its
 //    atom - to partialA[atom] / partialxA[atom].
 // ---------------------------------------------------------------------------------------------------
-template <bool EQUIV, int PREC, bool WEIGHTED>
+// ATT (GCL): edge attention m_ij *= sigmoid(w_att . m_ij + b_att), `vec4` = w_att' (times 1/c: the messages carry c), b_att = sc[8].
+// EQUIV with tanh: `head` = coords_range (0: no tanh), the head's output goes through coords_range * tanh(s).
+template <bool EQUIV, int PREC, bool WEIGHTED, bool ATT>
 __global__ void __launch_bounds__(EDGE_THREADS, 2)     // two waves per SIMD (two workgroups per CU): <= 256 VGPR + AGPR
 pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */,
-               const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index) {
+               const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index,
+               const float* __restrict__ vec4, float head) {
     __shared__ __attribute__((aligned(16))) float W[UNIT];
     __shared__ __attribute__((aligned(16))) float vec[4 * HID];
     const int tid = threadIdx.x;
@@ -432,14 +446,16 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         for (int e = tid; e < UNIT / 4; e += EDGE_THREADS) dst[e] = src[e];
         const int nv = EQUIV ? 4 : 3;
         for (int e = tid; e < nv * HID; e += EDGE_THREADS) vec[e] = vecs[e];
+        if (ATT) for (int e = tid; e < HID; e += EDGE_THREADS) vec[3 * HID + e] = vec4[e];
     }
     __syncthreads();
     float bias[4], w7[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         bias[nt] = vec[2 * HID + 32 * nt + c];
-        w7[nt] = EQUIV ? vec[3 * HID + 32 * nt + c] : 0.0f;
+        w7[nt] = (EQUIV || ATT) ? vec[3 * HID + 32 * nt + c] : 0.0f;
     }
+    const float att_b = ATT ? sc[8] : 0.0f;                         // b_att (dl_model_create keeps it in the pass's scale block)
     const float4* wrp = reinterpret_cast<const float4*>(vec + 64 * hh);
     const float4* wdp = reinterpret_cast<const float4*>(vec + HID + 64 * hh);
     const float4* Wp = reinterpret_cast<const float4*>(W) + (64 * hh * 32 + c);
@@ -624,11 +640,19 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                     for (int k = 0; k < 4; ++k) {
                         const int reg = 4 * g + k;
                         // WEIGHTED: the int8 mask value of the edge (0 on padding); else 1 on real edges, 0 on padding
-                        const float m = WEIGHTED ? w.wgt[size_t(t) * 32 + acc_row(reg, hh)] : float((vm >> (8 * g + k)) & 1u);
-                        s0 = fmaf(m, silu_u(acc0[reg]), s0);
-                        s1 = fmaf(m, silu_u(acc1[reg]), s1);
-                        s2 = fmaf(m, silu_u(acc2[reg]), s2);
-                        s3 = fmaf(m, silu_u(acc3[reg]), s3);
+                        float m = WEIGHTED ? w.wgt[size_t(t) * 32 + acc_row(reg, hh)] : float((vm >> (8 * g + k)) & 1u);
+                        const float u0 = silu_u(acc0[reg]), u1 = silu_u(acc1[reg]), u2 = silu_u(acc2[reg]), u3 = silu_u(acc3[reg]);
+                        if (ATT) {
+                            // one logit per edge over its 128 features: this lane half's 32 lanes x 4 feature tiles
+                            float lg = w7[0] * u0;
+                            lg = fmaf(w7[1], u1, lg); lg = fmaf(w7[2], u2, lg); lg = fmaf(w7[3], u3, lg);
+                            lg = half32_allsum(lg) + att_b;
+                            m *= __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * lg));
+                        }
+                        s0 = fmaf(m, u0, s0);
+                        s1 = fmaf(m, u1, s1);
+                        s2 = fmaf(m, u2, s2);
+                        s3 = fmaf(m, u3, s3);
                     }
                     sq[0][g] = s0; sq[1][g] = s1; sq[2][g] = s2; sq[3][g] = s3;
                 }
@@ -661,6 +685,8 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 both_halves(ts, lo, hi);
                 s_own = (reg == my_reg) ? (want_hi ? hi : lo) : s_own;
             }
+            if (head != 0.0f)                                        // tanh(s) * coords_range (egnn.py:104-105); uniform
+                s_own = head * (1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * s_own)));
             const float den = sqrtf(r + 1e-8f) + d.norm_constant;   // coord2diff, egnn.py:299-300
             float f = (hh == 0 && valid) ? s_own : 0.0f;
             if (WEIGHTED) f *= w.wgt[size_t(t) * 32 + c];
@@ -717,6 +743,9 @@ __global__ void pk_xupdate_kernel(PkDims d, PkWs w, const float* __restrict__ li
             ax += p.x; ay += p.y; az += p.z;
         }
     }
+    // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
+    const float xs = d.mean ? 1.0f / float(d.graph_type == 3 ? d.N : max(w.deg[v], 1)) : (d.tanh ? d.inv_norm : 1.0f);
+    ax *= xs; ay *= xs; az *= xs;
     const float lm = linker_mask ? linker_mask[v] : 1.0f;
     const float nm = (w.flags[v] & F_REAL) ? 1.0f : 0.0f;
     float4 x = *reinterpret_cast<const float4*>(w.X + 4 * v);
@@ -801,18 +830,30 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
         if (f16) hipLaunchKernelGGL(pk_node_kernel<1>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
         else hipLaunchKernelGGL(pk_node_kernel<0>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
     };
-    auto edge = [&](bool equiv, const float* wimg, const float* vecs, const float* sc, int sw) {
+    d.attention = md.attention; d.tanh = md.tanh; d.mean = md.mean; d.coords_range = md.coords_range; d.inv_norm = md.inv_norm;
+    // edge pass of a GCL (equiv = false; `vec4` = w_att' with attention) or of the coordinate head (equiv = true;
+    // `head` = coords_range with tanh)
+    auto edge = [&](bool equiv, const float* wimg, const float* vecs, const float* sc, int sw, const float* vec4, float head) {
+#define DL_EDGE(E, P, W, A) hipLaunchKernelGGL((pk_edge_kernel<E, P, W, A>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw, vec4, head)
         if (!equiv) {
-            if (f16 && weighted) hipLaunchKernelGGL((pk_edge_kernel<false, 1, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else if (f16) hipLaunchKernelGGL((pk_edge_kernel<false, 1, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else if (weighted) hipLaunchKernelGGL((pk_edge_kernel<false, 0, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else hipLaunchKernelGGL((pk_edge_kernel<false, 0, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            if (md.attention) {
+                if (f16 && weighted) DL_EDGE(false, 1, true, true);
+                else if (f16) DL_EDGE(false, 1, false, true);
+                else if (weighted) DL_EDGE(false, 0, true, true);
+                else DL_EDGE(false, 0, false, true);
+            } else {
+                if (f16 && weighted) DL_EDGE(false, 1, true, false);
+                else if (f16) DL_EDGE(false, 1, false, false);
+                else if (weighted) DL_EDGE(false, 0, true, false);
+                else DL_EDGE(false, 0, false, false);
+            }
         } else {
-            if (f16 && weighted) hipLaunchKernelGGL((pk_edge_kernel<true, 1, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else if (f16) hipLaunchKernelGGL((pk_edge_kernel<true, 1, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else if (weighted) hipLaunchKernelGGL((pk_edge_kernel<true, 0, true>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
-            else hipLaunchKernelGGL((pk_edge_kernel<true, 0, false>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw);
+            if (f16 && weighted) DL_EDGE(true, 1, true, false);
+            else if (f16) DL_EDGE(true, 1, false, false);
+            else if (weighted) DL_EDGE(true, 0, true, false);
+            else DL_EDGE(true, 0, false, false);
         }
+#undef DL_EDGE
     };
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
@@ -821,11 +862,11 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
         const float* eq = base + 2 * GCL_SIZE;
         // projections for gcl_0 (the previous block's node kernel already produced them, except for block 0)
         if (blk == 0) node(nullptr, g0 + G_W1A, g0 + G_VEC, g0 + G_SCALE);
-        edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5);
+        edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5, g0 + G_VEC + 6 * HID, 0.0f);
         node(g0, g1 + G_W1A, g1 + G_VEC, g1 + G_SCALE);
-        edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5);
+        edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5, g1 + G_VEC + 6 * HID, 0.0f);
         node(g1, eq + E_W5A, eq + E_VEC, eq + E_SCALE);
-        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2);
+        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2, nullptr, md.tanh ? md.coords_range : 0.0f);
         hipLaunchKernelGGL(pk_xupdate_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d, w, linker_mask);
         if (blk + 1 < md.n_layers) {
             const float* n0 = base + BLOCK_SIZE;                   // next block's gcl_0 projections (h unchanged)
@@ -847,7 +888,6 @@ int32_t dl_egnn_forward_pocket(const dl_model* m, int32_t B, int32_t N, int32_t 
         return DL_ERR_BAD_ARG;
     if (B < 0 || N < 1 || graph_type < 0 || graph_type > 2) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf < 2) return DL_ERR_BAD_ARG;                      // needs the fragment/pocket channels
-    if (m->cfg.attention || m->cfg.tanh || m->cfg.aggregation_mean) return DL_ERR_UNSUPPORTED;   // optional hparams: FC kernels only
     return run_sparse(m, B, N, graph_type, xh, t, t_is_scalar, node_mask, linker_mask, nullptr, context, out, nan_flags,
                       workspace, workspace_bytes, stream);
 }
@@ -858,7 +898,6 @@ int32_t dl_egnn_forward_fc_large(const dl_model* m, int32_t B, int32_t N, const 
                                  void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !xh || !t || !node_mask || !edge_mask || !out || !nan_flags || !workspace) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
-    if (m->cfg.attention || m->cfg.tanh || m->cfg.aggregation_mean) return DL_ERR_UNSUPPORTED;   // optional hparams: LDS-resident kernels only
     if (B < 0 || N < 1) return DL_ERR_BAD_ARG;
     return run_sparse(m, B, N, 3, xh, t, t_is_scalar, node_mask, linker_mask, edge_mask, context, out, nan_flags, workspace,
                       workspace_bytes, stream);

@@ -383,7 +383,7 @@ class EDM(torch.nn.Module):
         noise_h = torch.empty((self.T + 2, n_samples, n_nodes, self.in_node_nf), device=device)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(_lib.load().dl_philox_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset), n_samples, n_nodes,
+            _lib.check(_lib.load().dl_philox_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset), None, n_samples, n_nodes,
                                                   self.in_node_nf, 0, self.T + 2, noise_x.data_ptr(), noise_h.data_ptr(),
                                                   ctypes.c_void_p(stream)), 'dl_philox_fill')
         return noise_x, noise_h
@@ -401,14 +401,15 @@ class EDM(torch.nn.Module):
             first = int(st[f != 0].min())
             raise utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
 
-    def _philox_draw(self, seed, mol_offset, k, n_samples, n_nodes, device):
-        """Draw number ``k`` of the in-kernel stream as one ``[B,N,3+nf]`` tensor (``dl_philox_fill`` with one draw)."""
+    def _philox_draw(self, seed, mol_offset, k, n_samples, n_nodes, device, mol_index=None):
+        """Draw number ``k`` of the in-kernel stream as one ``[B,N,3+nf]`` tensor (``dl_philox_fill`` with one draw);
+        ``mol_index`` (device int32 ``[B]``): the rows of these molecules of a larger batch, and nothing else."""
         nx = torch.empty((1, n_samples, n_nodes, self.n_dims), device=device)
         nh = torch.empty((1, n_samples, n_nodes, self.in_node_nf), device=device)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
-            _lib.check(_lib.load().dl_philox_fill(seed, mol_offset, n_samples, n_nodes, self.in_node_nf, k, 1, nx.data_ptr(),
-                                                  nh.data_ptr(), ctypes.c_void_p(stream)), 'dl_philox_fill')
+            _lib.check(_lib.load().dl_philox_fill(seed, mol_offset, _lib.ptr(mol_index), n_samples, n_nodes, self.in_node_nf, k, 1,
+                                                  nx.data_ptr(), nh.data_ptr(), ctypes.c_void_p(stream)), 'dl_philox_fill')
         return torch.cat([nx[0], nh[0]], dim=2)
 
     def _sample_chain_host_loop(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames,
@@ -427,7 +428,8 @@ class EDM(torch.nn.Module):
                 return torch.cat([noise_bank[0][k].to(dev, torch.float32), noise_bank[1][k].to(dev, torch.float32)], dim=2)
             if philox_draws is not None:
                 if len(philox_draws) == 4:       # (seed, mol_offset, rows, size of the whole batch): a non-contiguous part of it
-                    return self._philox_draw(philox_draws[0], philox_draws[1], k, philox_draws[3], n_nodes, dev)[philox_draws[2]]
+                    rows = philox_draws[2].to(torch.int32).contiguous()
+                    return self._philox_draw(philox_draws[0], philox_draws[1], k, n_samples, n_nodes, dev, mol_index=rows)
                 return self._philox_draw(philox_draws[0], philox_draws[1], k, n_samples, n_nodes, dev)
             return torch.cat([torch.randn((n_samples, n_nodes, self.n_dims), device=dev),
                               torch.randn((n_samples, n_nodes, self.in_node_nf), device=dev)], dim=2)

@@ -170,10 +170,8 @@ class Dynamics(nn.Module):
             # reference: 'gnn_dynamics' builds a plain GNN, anything else NotImplementedError (egnn.py:355-370)
             raise NotImplementedError(f"model={model!r}: the HIP path implements 'egnn_dynamics' only")
         unsupported = []
-        # attention, tanh and aggregation_method='mean' run in the LDS-resident fully-connected kernels; the pocket /
-        # large-molecule kernels do not carry them (no released configuration uses any of them)
-        if (attention or tanh or aggregation_method != 'sum') and (graph_type != 'FC' or type(self).__name__ != 'Dynamics'):
-            unsupported.append('attention / tanh / mean aggregation with a pocket graph')
+        # attention, tanh and aggregation_method='mean' run in every kernel family (round 3: the pocket / large-molecule kernels
+        # too); no released configuration uses any of them
         if sin_embedding: unsupported.append('sin_embedding=True')
         if aggregation_method not in ('sum', 'mean'): unsupported.append(f'aggregation_method={aggregation_method!r}')
         if not isinstance(activation, nn.SiLU): unsupported.append(f'activation={activation!r}')
@@ -340,9 +338,6 @@ class Dynamics(nn.Module):
             for chunk in self.team_chunks(med, dev):
                 parts.append(part(chunk, False, team=max(2, self.team_for_size(int(chunk.numel()), dev))))
         if big is not None:
-            if self._flags():
-                raise NotImplementedError('attention / tanh / mean aggregation are not carried by the HBM-resident kernels that '
-                                          f'molecules of more than {self._atom_limit()} atoms run on')
             parts.append(part(big, True))
         if len(parts) == 1 and parts[0]['bs'] == bs:               # one class only: no scatter needed
             prep.update(large=parts[0]['large'], team=parts[0]['team'])

@@ -90,13 +90,14 @@ typedef struct dl_config {
     float norm_constant;          /* 1e-6 in the released configs                   */
     float normalization_factor;   /* 100                                            */
     int32_t precision;            /* dl_precision: arithmetic of the 128-wide GEMMs */
-    /* optional hyper-parameters of the reference no released configuration uses; fully-connected path only (the pocket /
-     * large-molecule entry points return DL_ERR_UNSUPPORTED for a model that sets one): */
+    /* optional hyper-parameters of the reference no released configuration uses (every entry point carries them; round 3:
+     * dl_egnn_forward_pocket and dl_egnn_forward_fc_large too): */
     int32_t attention;            /* GCL edge attention: m_ij *= sigmoid(w_att . m_ij + b_att)   src/egnn.py:42-43,52-54  */
     int32_t tanh;                 /* coordinate head: cdiff * tanh(s) * coords_range             src/egnn.py:104-105      */
     float coords_range;           /* 15 for Dynamics (EGNN hands its undivided default to the blocks, src/egnn.py:183,213) */
     int32_t aggregation_mean;     /* 0: sum / normalization_factor; 1: / number of edges of the row, masked ones included
-                                   * (= the padded width N on the fully-connected graph)          src/egnn.py:315-319      */
+                                   * (= the padded width N on the fully-connected graph, the atom's degree on a radius
+                                   * graph)                                                        src/egnn.py:315-319      */
     int32_t sin_embedding;        /* must be 0 (src/egnn.py:281-292: not in the kernels)                                   */
 } dl_config;
 
@@ -267,9 +268,11 @@ int32_t dl_inpaint_step(int32_t B, int32_t N, int32_t nf, const float* z_t, cons
                         dl_inpaint_coef coef, float* z_s, void* stream);
 
 /* The in-kernel noise stream as a bank (for host-driven loops and tests): Philox4x32-10, key = seed, counter =
- * (mol_offset + b, atom position n, draw0 + k, component / 4), four outputs -> four standard normals by Box-Muller;
- * component d < 3 is noise_x[k][b][n][d], d >= 3 is noise_h[k][b][n][d-3].  Independent of the batch split. */
-int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, int32_t B, int32_t N, int32_t nf, int32_t draw0,
+ * (mol_offset + m(b), atom position n, draw0 + k, component / 4) with m(b) = mol_index[b] (device int32 [B]) or b when mol_index
+ * is NULL - the same keying as dl_chain_args.mol_offset / mol_index, so a part of a batch gets exactly its own rows;
+ * four outputs -> four standard normals by Box-Muller; component d < 3 is noise_x[k][b][n][d], d >= 3 is noise_h[k][b][n][d-3].
+ * Independent of the batch split. */
+int32_t dl_philox_fill(uint64_t seed, int32_t mol_offset, const int32_t* mol_index, int32_t B, int32_t N, int32_t nf, int32_t draw0,
                        int32_t n_draws, float* noise_x, float* noise_h, void* stream);
 
 /* Diagnostics (libraries built with -DDL_PROFILE only; dl_profile_max_events() returns 0 otherwise): when set

@@ -71,20 +71,41 @@ def test_flags_chain_vs_oracle():
     P.check_chain('chain with attention + tanh + mean', got, want, inp)
 
 
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+@pytest.mark.parametrize('case', HIP_CASES, ids=[c[0] for c in HIP_CASES])
+def test_flags_on_the_pocket_graph_vs_oracle(case, precision):
+    """Round 3: the optional hyper-parameters in the radius-graph kernels too (csrc/egnn_sparse.hip): attention per edge,
+    tanh head, 'mean' = division by the receiving atom's degree (every edge of its row counts, egnn.py:315-319)."""
+    from difflinker_amd import DynamicsWithPockets
+    tag, flags = case
+    nf, L = 9, 2
+    dyn = DynamicsWithPockets(n_dims=3, in_node_nf=nf, context_node_nf=2, hidden_nf=128, n_layers=L, norm_constant=1e-6,
+                              normalization='batch_norm', graph_type='FC-10A-4A', **flags)
+    dyn.precision = precision
+    sd = seeded_state_dict(nf + 3, 128, L, 240, coord_gain=1.0 if flags.get('tanh') else 0.02, attention=bool(flags.get('attention')))
+    dyn.load_state_dict(sd, strict=True)
+    dyn = dyn.to(P.dev())
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=2, n_layers=L, graph_type='FC-10A-4A', **flags)
+    inp, z, t = P.pocket_inputs(batch=3, n_frag=14, n_pocket=90, linker=(5, 9), nf=nf, seed=241)
+    ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    ev, eh = P.report(f'pocket flags [{tag}] {precision}', P.run_hip_forward(dyn, inp, z, t), ref, z)
+    assert ev <= P.FWD_TOLS[precision] and eh <= P.FWD_TOLS[precision]
+    assert float(ref[..., :3].abs().max()) > 1e-5, 'the coordinate head must act in this case'
+
+
 def test_unsupported_combinations_raise():
-    from difflinker_amd import Dynamics, DynamicsWithPockets
+    from difflinker_amd import Dynamics
     with pytest.raises(NotImplementedError):
         Dynamics(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1, sin_embedding=True)
-    with pytest.raises(NotImplementedError):
-        DynamicsWithPockets(n_dims=3, in_node_nf=9, context_node_nf=2, hidden_nf=128, n_layers=1, attention=True,
-                            graph_type='FC-10A-4A')
     # 56..110 atoms: a team of compute units per molecule, the same kernels, the options included
     dyn, sd, cfg = make(9, 1, 1, 230, dict(tanh=True, attention=True, aggregation_method='mean'), 'f16x3', 1.0)
     inp, z, t = P.ragged_inputs([60, 20], [5, 4], 9, seed=231)
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     ev, eh = P.report('flags on a 60-atom molecule (team)', P.run_hip_forward(dyn, inp, z, t), ref, z)
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
-    # beyond that a molecule leaves the kernels that carry the options: refused before anything is launched, not silently wrong
+    # beyond 110 atoms: the HBM-resident kernels on the reference's dense masked edge list, options included ('mean' counts the
+    # padded row width there, like the reference's edge list)
     inp, z, t = P.ragged_inputs([120, 20], [5, 4], 9, seed=232)
-    with pytest.raises(NotImplementedError):
-        P.run_hip_forward(dyn, inp, z, t)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    ev, eh = P.report('flags on a 120-atom molecule (HBM-resident kernels)', P.run_hip_forward(dyn, inp, z, t), ref, z)
+    assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
