@@ -1949,6 +1949,21 @@ float row_l1(const float* w, int ld, int col0, double scale) {
     return float(m * 1.0001);
 }
 
+// sin_embedding: dst[k][f] = scale * W[f][256 + k], k < 24; returns the largest row L1 norm (a bound on the term: |sin|, |cos| <= 1)
+float pack_sin_columns(float* dst, const float* w, int ld, double scale) {
+    double m = 0.0;
+    for (int f = 0; f < HID; ++f) {
+        double r = 0.0;
+        for (int k = 0; k < SIN_K; ++k) {
+            const double v = double(w[size_t(f) * ld + 2 * HID + k]) * scale;
+            dst[k * HID + f] = float(v);
+            r += fabs(v);
+        }
+        m = fmax(m, r);
+    }
+    return float(m * 1.0001);
+}
+
 float vec_absmax(const float* v) {
     float m = 0.0f;
     for (int f = 0; f < HID; ++f) m = fmaxf(m, fabsf(v[f]));
@@ -1997,7 +2012,7 @@ static int32_t check_cfg(const dl_config* c) {
     if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
     if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_F16X3) return DL_ERR_UNSUPPORTED;
     if ((c->attention | 1) != 1 || (c->tanh | 1) != 1 || (c->aggregation_mean | 1) != 1) return DL_ERR_BAD_ARG;
-    if (c->sin_embedding != 0) return DL_ERR_UNSUPPORTED;
+    if ((c->sin_embedding | 1) != 1) return DL_ERR_BAD_ARG;
     if (c->tanh && !(c->coords_range > 0.0f)) return DL_ERR_BAD_ARG;
     return DL_OK;
 }
@@ -2056,7 +2071,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             const float* w4 = w[ti++]; const float* b4 = w[ti++];     // node_mlp.2 [128][128]
             const float* watt = nullptr; const float* batt = nullptr;
             if (cfg->attention) { watt = w[ti++]; batt = w[ti++]; }   // att_mlp.0 [1][128], [1]
-            const int ld1 = 2 * HID + 2;
+            const int ld1 = 2 * HID + (cfg->sin_embedding ? SIN_K : 2);
             float* sc = g + G_SCALE;
             sc[0] = unit(g + G_W1A, w1, ld1, 0, c);
             sc[1] = unit(g + G_W1B, w1, ld1, HID, c);
@@ -2069,8 +2084,12 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             image_t(g + G_W2T, w2, HID, 1.0);
             float* vv = g + G_VEC;
             pack_vec(vv + 0 * HID, b1, 1, c);
-            pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);             // radial column
-            pack_vec(vv + 2 * HID, w1 + 2 * HID + 1, ld1, c);         // d0 column
+            if (!cfg->sin_embedding) {
+                pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);         // radial column
+                pack_vec(vv + 2 * HID, w1 + 2 * HID + 1, ld1, c);     // d0 column
+            } else {
+                sc[20] = pack_sin_columns(g + G_WG, w1, ld1, c);      // 24 embedded-distance columns; sc[20] = largest row L1 norm
+            }
             pack_vec(vv + 3 * HID, b2, 1, c);
             pack_vec(vv + 4 * HID, b3, 1, c);
             pack_vec(vv + 5 * HID, b4, 1, 1.0);
@@ -2088,7 +2107,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         const float* w5 = w[ti++]; const float* b5 = w[ti++];         // coord_mlp.0 [128][258]
         const float* w6 = w[ti++]; const float* b6 = w[ti++];         // coord_mlp.2 [128][128]
         const float* w7 = w[ti++];                                    // coord_mlp.4 [1][128], no bias
-        const int ld5 = 2 * HID + 2;
+        const int ld5 = 2 * HID + (cfg->sin_embedding ? SIN_K : 2);
         float* sc = e + E_SCALE;
         sc[0] = unit(e + E_W5A, w5, ld5, 0, c);
         sc[1] = unit(e + E_W5B, w5, ld5, HID, c);
@@ -2096,8 +2115,12 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         image_t(e + E_W6T, w6, HID, 1.0);
         float* vv = e + E_VEC;
         pack_vec(vv + 0 * HID, b5, 1, c);
-        pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
-        pack_vec(vv + 2 * HID, w5 + 2 * HID + 1, ld5, c);
+        if (!cfg->sin_embedding) {
+            pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
+            pack_vec(vv + 2 * HID, w5 + 2 * HID + 1, ld5, c);
+        } else {
+            sc[11] = pack_sin_columns(e + E_WG, w5, ld5, c);
+        }
         pack_vec(vv + 3 * HID, b6, 1, c);
         // s = w7 . SiLU(..): with tanh or the mean the head's raw output is needed, the normalisation follows at run time
         pack_vec(vv + 4 * HID, w7, 1, (cfg->tanh || cfg->aggregation_mean) ? 1.0 / c : inv_norm / c);
@@ -2108,6 +2131,13 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     dl_model* m = static_cast<dl_model*>(calloc(1, sizeof(dl_model)));
     if (!m) { free(hp); return DL_ERR_ALLOC; }
     m->cfg = *cfg;
+    if (cfg->sin_embedding)
+        for (int blk = 0; blk < L; ++blk) {
+            const float* base = hp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
+            m->sin_l1[blk * 3 + 0] = base[G_SCALE + 20];
+            m->sin_l1[blk * 3 + 1] = base[GCL_SIZE + G_SCALE + 20];
+            m->sin_l1[blk * 3 + 2] = base[2 * GCL_SIZE + E_SCALE + 11];
+        }
     m->n_floats = total;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { free(hp); free(m); return DL_ERR_NO_DEVICE; }
@@ -2194,6 +2224,7 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
                                 int32_t team, void* workspace, size_t workspace_bytes, void* stream) {
     if (!m || !xh || !t || !node_mask || !out || !nan_flags || B < 0 || N < 1) return DL_ERR_BAD_ARG;
     if (m->cfg.context_node_nf > 0 && !context) return DL_ERR_BAD_ARG;
+    if (m->cfg.sin_embedding) return DL_ERR_UNSUPPORTED;       // sinusoidal distance embedding: dl_egnn_forward_fc_large / _pocket only
     if (B == 0) return DL_OK;
     FwdArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.B = B; a.N = N; a.xh = xh; a.t = t;
@@ -2231,6 +2262,7 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if ((g->noise_x == nullptr) != (g->noise_h == nullptr)) return DL_ERR_BAD_ARG;    // both (bank) or neither (Philox)
     if (m->cfg.context_node_nf > 0 && !g->context) return DL_ERR_BAD_ARG;
     if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T || g->team < 0) return DL_ERR_BAD_ARG;
+    if (m->cfg.sin_embedding) return DL_ERR_UNSUPPORTED;       // (host-driven loop over dl_egnn_forward_fc_large instead)
     if (g->B == 0) return DL_OK;
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;

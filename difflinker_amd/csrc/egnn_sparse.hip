@@ -37,6 +37,7 @@ struct PkDims {
     // optional hyper-parameters (round 3; src/egnn.py:42-43,52-54 attention, :104-105 tanh, :315-319 mean)
     int attention, tanh, mean;
     float coords_range, inv_norm;
+    int sin;                             // sinusoidal distance embedding (egnn.py:281-292): the edge attributes are 2 x 12 sin / cos values
 };
 
 // workspace carve-up (all offsets in bytes, 256-B aligned)
@@ -430,13 +431,32 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
 // ---------------------------------------------------------------------------------------------------
 // ATT (GCL): edge attention m_ij *= sigmoid(w_att . m_ij + b_att), `vec4` = w_att' (times 1/c: the messages carry c), b_att = sc[8].
 // EQUIV with tanh: `head` = coords_range (0: no tanh), the head's output goes through coords_range * tanh(s).
-template <bool EQUIV, int PREC, bool WEIGHTED, bool ATT>
+// SIN: sin_embedding - the rank-2 term wr' r + wd' d0 of the first layer becomes a 24-term sum over the embedded distances
+// sin / cos(sqrt(. + 1e-8) * f_k), f_k = 2 pi 4^k / 15 (egnn.py:281-292; radial: :159-161, d0: :221-222), `wg` = their weight
+// columns [24][128].  The arithmetic up to the sine's argument follows the reference operation by operation (the top frequency
+// turns one ulp of the distance into 1e-4 of phase), sinf / cosf are the accurate library versions.
+__device__ __forceinline__ void sin_embed(float r, float d0, float (&e)[SIN_K]) {
+    const float two_pi = 6.283185307179586f;
+    const float dr = __fsqrt_rn(__fadd_rn(r, 1e-8f)), dd = __fsqrt_rn(__fadd_rn(d0, 1e-8f));
+    float f4 = 1.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float fk = __fdiv_rn(__fmul_rn(two_pi, f4), 15.0f);
+        const float a = __fmul_rn(dr, fk), b = __fmul_rn(dd, fk);
+        e[k] = sinf(a); e[6 + k] = cosf(a);
+        e[12 + k] = sinf(b); e[18 + k] = cosf(b);
+        f4 *= 4.0f;
+    }
+}
+
+template <bool EQUIV, int PREC, bool WEIGHTED, bool ATT, bool SIN>
 __global__ void __launch_bounds__(EDGE_THREADS, 2)     // two waves per SIMD (two workgroups per CU): <= 256 VGPR + AGPR
 pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */,
                const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index,
-               const float* __restrict__ vec4, float head) {
+               const float* __restrict__ vec4, float head, const float* __restrict__ wg, float wg_l1) {
     __shared__ __attribute__((aligned(16))) float W[UNIT];
     __shared__ __attribute__((aligned(16))) float vec[4 * HID];
+    __shared__ __attribute__((aligned(16))) float WG[SIN ? SIN_K * HID : 4];
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, c = lane & 31, hh = lane >> 5;
@@ -447,6 +467,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         const int nv = EQUIV ? 4 : 3;
         for (int e = tid; e < nv * HID; e += EDGE_THREADS) vec[e] = vecs[e];
         if (ATT) for (int e = tid; e < HID; e += EDGE_THREADS) vec[3 * HID + e] = vec4[e];
+        if (SIN) for (int e = tid; e < SIN_K * HID; e += EDGE_THREADS) WG[e] = wg[e];
     }
     __syncthreads();
     float bias[4], w7[4];
@@ -496,8 +517,13 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         const float4 yj = *reinterpret_cast<const float4*>(w.X0 + 4 * j0);
         dx = xi.x - xj.x; dy = xi.y - xj.y; dz = xi.z - xj.z;
         const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
-        r = dx * dx + dy * dy + dz * dz;
-        d0 = ex * ex + ey * ey + ez * ez;
+        if (SIN) {                                                   // torch.sum(coord_diff ** 2, 1): products, then two additions
+            r = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            d0 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+        } else {
+            r = dx * dx + dy * dy + dz * dz;
+            d0 = ex * ex + ey * ey + ez * ez;
+        }
         if (PREC == 1) pqb = w.pmax[i] + w.qmax[j0];
     }
     // rows of the CURRENT tile (requested one tile ahead): the P rows of the quads' receiving atoms and the 32 senders' Q rows
@@ -545,17 +571,28 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             if (PREC == 1) pq_n = w.pmax[i_n] + w.qmax[jn0];
             request_rows(i_n, jn0, p2n, qn);
         };
+        float emb[SIN ? SIN_K : 1];
+        if constexpr (SIN) sin_embed(r, d0, emb);
         if constexpr (PREC == 0) {
             float a[64];
             {
                 const float4* Pp = reinterpret_cast<const float4*>(pst + qg * LDT + 64 * hh);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
-                    const float4 P = Pp[q], Q = qv[q], wr = wrp[q], wd = wdp[q];
-                    a[4 * q + 0] = silu_u(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)));
-                    a[4 * q + 1] = silu_u(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)));
-                    a[4 * q + 2] = silu_u(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)));
-                    a[4 * q + 3] = silu_u(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)));
+                    const float4 P = Pp[q], Q = qv[q];
+                    float4 y = make_float4(P.x + Q.x, P.y + Q.y, P.z + Q.z, P.w + Q.w);
+                    if (SIN) {
+#pragma unroll
+                        for (int k = 0; k < SIN_K; ++k) {
+                            const float4 g4 = *reinterpret_cast<const float4*>(WG + k * HID + 64 * hh + 4 * q);
+                            y.x = fmaf(emb[k], g4.x, y.x); y.y = fmaf(emb[k], g4.y, y.y); y.z = fmaf(emb[k], g4.z, y.z); y.w = fmaf(emb[k], g4.w, y.w);
+                        }
+                    } else {
+                        const float4 wr = wrp[q], wd = wdp[q];
+                        y.x = fmaf(d0, wd.x, fmaf(r, wr.x, y.x)); y.y = fmaf(d0, wd.y, fmaf(r, wr.y, y.y));
+                        y.z = fmaf(d0, wd.z, fmaf(r, wr.z, y.z)); y.w = fmaf(d0, wd.w, fmaf(r, wr.w, y.w));
+                    }
+                    a[4 * q + 0] = silu_u(y.x); a[4 * q + 1] = silu_u(y.y); a[4 * q + 2] = silu_u(y.z); a[4 * q + 3] = silu_u(y.w);
                 }
             }
             request_next_geometry();
@@ -571,7 +608,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             }
         } else {
             // f16x3: |u| <= |y| <= max|P_i| + max|Q_j| + r*max|wr'| + d0*max|wd'|; the tile's largest bound sets the scale
-            float bound = pqb + r * sc[6] + d0 * sc[7];
+            float bound = SIN ? pqb + wg_l1 : pqb + r * sc[6] + d0 * sc[7];
             bound = fmaxf(bound, dpp_mov<0xB1>(bound));
             bound = fmaxf(bound, dpp_mov<0x4E>(bound));
             bound = fmaxf(bound, dpp_mov<0x141>(bound));
@@ -600,12 +637,21 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                     const int k0 = 16 * slab + 4 * q;
                     const float4 P = *reinterpret_cast<const float4*>(Pp + k0);
                     const float4 Q = qv[2 * slab + q];
-                    const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
-                    const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
-                    us[4 * q + 0] = silu_scaled(fmaf(d0, wd.x, fmaf(r, wr.x, P.x + Q.x)), isa);
-                    us[4 * q + 1] = silu_scaled(fmaf(d0, wd.y, fmaf(r, wr.y, P.y + Q.y)), isa);
-                    us[4 * q + 2] = silu_scaled(fmaf(d0, wd.z, fmaf(r, wr.z, P.z + Q.z)), isa);
-                    us[4 * q + 3] = silu_scaled(fmaf(d0, wd.w, fmaf(r, wr.w, P.w + Q.w)), isa);
+                    float4 y = make_float4(P.x + Q.x, P.y + Q.y, P.z + Q.z, P.w + Q.w);
+                    if (SIN) {
+#pragma unroll
+                        for (int k = 0; k < SIN_K; ++k) {
+                            const float4 g4 = *reinterpret_cast<const float4*>(WG + k * HID + 8 * hh + k0);
+                            y.x = fmaf(emb[k], g4.x, y.x); y.y = fmaf(emb[k], g4.y, y.y); y.z = fmaf(emb[k], g4.z, y.z); y.w = fmaf(emb[k], g4.w, y.w);
+                        }
+                    } else {
+                        const float4 wr = *reinterpret_cast<const float4*>(wrb + k0);
+                        const float4 wd = *reinterpret_cast<const float4*>(wdb + k0);
+                        y.x = fmaf(d0, wd.x, fmaf(r, wr.x, y.x)); y.y = fmaf(d0, wd.y, fmaf(r, wr.y, y.y));
+                        y.z = fmaf(d0, wd.z, fmaf(r, wr.z, y.z)); y.w = fmaf(d0, wd.w, fmaf(r, wr.w, y.w));
+                    }
+                    us[4 * q + 0] = silu_scaled(y.x, isa); us[4 * q + 1] = silu_scaled(y.y, isa);
+                    us[4 * q + 2] = silu_scaled(y.z, isa); us[4 * q + 3] = silu_scaled(y.w, isa);
                 }
                 uint4 ah, al;
                 split8(us, ah, al);
@@ -715,8 +761,13 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
         dx = xn[0] - xn[3]; dy = xn[1] - xn[4]; dz = xn[2] - xn[5];
         {
             const float ex = xn[6] - xn[9], ey = xn[7] - xn[10], ez = xn[8] - xn[11];
-            r = dx * dx + dy * dy + dz * dz;
-            d0 = ex * ex + ey * ey + ez * ez;
+            if (SIN) {
+                r = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                d0 = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+            } else {
+                r = dx * dx + dy * dy + dz * dz;
+                d0 = ex * ex + ey * ey + ez * ez;
+            }
         }
         pqb = pq_n;
 #pragma unroll
@@ -831,10 +882,13 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
         else hipLaunchKernelGGL(pk_node_kernel<0>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
     };
     d.attention = md.attention; d.tanh = md.tanh; d.mean = md.mean; d.coords_range = md.coords_range; d.inv_norm = md.inv_norm;
+    d.sin = md.sin;
     // edge pass of a GCL (equiv = false; `vec4` = w_att' with attention) or of the coordinate head (equiv = true;
     // `head` = coords_range with tanh)
-    auto edge = [&](bool equiv, const float* wimg, const float* vecs, const float* sc, int sw, const float* vec4, float head) {
-#define DL_EDGE(E, P, W, A) hipLaunchKernelGGL((pk_edge_kernel<E, P, W, A>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw, vec4, head)
+    auto edge = [&](bool equiv, const float* wimg, const float* vecs, const float* sc, int sw, const float* vec4, float head,
+                    const float* wg, float wg_l1) {
+#define DL_EDGE5(E, P, W, A, S) hipLaunchKernelGGL((pk_edge_kernel<E, P, W, A, S>), dim3(edge_grid), dim3(EDGE_THREADS), 0, st, d, w, wimg, vecs, sc, sw, vec4, head, wg, wg_l1)
+#define DL_EDGE(E, P, W, A) do { if (md.sin) DL_EDGE5(E, P, W, A, true); else DL_EDGE5(E, P, W, A, false); } while (0)
         if (!equiv) {
             if (md.attention) {
                 if (f16 && weighted) DL_EDGE(false, 1, true, true);
@@ -854,6 +908,12 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
             else DL_EDGE(true, 0, false, false);
         }
 #undef DL_EDGE
+#undef DL_EDGE5
+    };
+    // sin_embedding: the largest row L1 norm of the embedded-distance columns bounds their term (host copy of the pass's scale slot)
+    auto wg_bound = [&](int blk, int which) -> float {
+        if (!md.sin) return 0.0f;
+        return m->sin_l1[size_t(blk) * 3 + which];
     };
     for (int blk = 0; blk < md.n_layers; ++blk) {
         const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
@@ -862,11 +922,11 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
         const float* eq = base + 2 * GCL_SIZE;
         // projections for gcl_0 (the previous block's node kernel already produced them, except for block 0)
         if (blk == 0) node(nullptr, g0 + G_W1A, g0 + G_VEC, g0 + G_SCALE);
-        edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5, g0 + G_VEC + 6 * HID, 0.0f);
+        edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5, g0 + G_VEC + 6 * HID, 0.0f, g0 + G_WG, wg_bound(blk, 0));
         node(g0, g1 + G_W1A, g1 + G_VEC, g1 + G_SCALE);
-        edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5, g1 + G_VEC + 6 * HID, 0.0f);
+        edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5, g1 + G_VEC + 6 * HID, 0.0f, g1 + G_WG, wg_bound(blk, 1));
         node(g1, eq + E_W5A, eq + E_VEC, eq + E_SCALE);
-        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2, nullptr, md.tanh ? md.coords_range : 0.0f);
+        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2, nullptr, md.tanh ? md.coords_range : 0.0f, eq + E_WG, wg_bound(blk, 2));
         hipLaunchKernelGGL(pk_xupdate_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d, w, linker_mask);
         if (blk + 1 < md.n_layers) {
             const float* n0 = base + BLOCK_SIZE;                   // next block's gcl_0 projections (h unchanged)

@@ -9,6 +9,7 @@ struct dl_model {
     dl_config cfg;
     float* d_pack;
     size_t n_floats;
+    float sin_l1[64 * 3];           // sin_embedding: per block, row L1 bound of the embedded-distance columns of gcl_0, gcl_1, gcl_equiv
 };
 
 namespace {
@@ -33,18 +34,21 @@ constexpr int G_W1A = 0, G_W1B = UNIT, G_W3A = 2 * UNIT, G_W3B = 3 * UNIT, G_W4 
 constexpr int G_VEC = 7 * UNIT;                       // b1', wr', wd', b2', b3', b4, w_att'   (7 x 128)
 constexpr int G_SCALE = G_VEC + 7 * HID;             // f16x3: sw(W1a',W1b',W3a',W3b',W4',W2'), |wr'|max, |wd'|max, b_att, -, -, -,
                                                      // [12..19] row L1 norms of W1a',W1b',W3a',W3b',W4', max |b1'|,|b3'|,|b4| (egnn_fc.hip)
-constexpr int GCL_SIZE = 7 * UNIT + 7 * HID + 24;
+constexpr int G_WG = G_SCALE + 24;                   // sin_embedding: the 24 embedded-distance columns of edge_mlp.0, [k][128], times c
+constexpr int SIN_K = 24;                            // 6 frequencies x (sin, cos) x (radial, d0)   (egnn.py:281-292, :159-161, :221-222)
+constexpr int GCL_SIZE = 7 * UNIT + 7 * HID + 24 + SIN_K * HID;
 // equivariant update: units W5a', W5b', W6' (both LDS images), vectors
 constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT, E_W6T = 3 * UNIT;
 constexpr int E_VEC = 4 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
 constexpr int E_SCALE = E_VEC + 5 * HID;             // f16x3: sw(W5a',W5b',W6'), -, -, -, |wr'|max, |wd'|max, L1(W5a'), L1(W5b'), max |b5'|
-constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + 16;
+constexpr int E_WG = E_SCALE + 16;                   // sin_embedding: the same for coord_mlp.0
+constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + 16 + SIN_K * HID;
 constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
 
 struct ModelDims {
     int nf, ctx, fin, n_layers;
     float norm_constant;
-    int attention, tanh, mean;     // optional hyper-parameters (fully-connected kernels only)
+    int attention, tanh, mean, sin;     // optional hyper-parameters (sin_embedding: the HBM-resident kernels only)
     float coords_range, inv_norm;
 };
 
@@ -55,7 +59,7 @@ inline ModelDims dims_of(const dl_model* m) {
     md.fin = md.nf + 1 + md.ctx;
     md.n_layers = m->cfg.n_layers;
     md.norm_constant = m->cfg.norm_constant;
-    md.attention = m->cfg.attention; md.tanh = m->cfg.tanh; md.mean = m->cfg.aggregation_mean;
+    md.attention = m->cfg.attention; md.tanh = m->cfg.tanh; md.mean = m->cfg.aggregation_mean; md.sin = m->cfg.sin_embedding;
     md.coords_range = m->cfg.coords_range; md.inv_norm = 1.0f / m->cfg.normalization_factor;
     return md;
 }

@@ -230,7 +230,7 @@ class EDM(torch.nn.Module):
     # ---- the chain ------------------------------------------------------------------------------------
     def _fused_ok(self):
         return isinstance(self.dynamics, Dynamics) and not isinstance(self.dynamics, DynamicsWithPockets) \
-            and self.dynamics.graph_type == 'FC' and not self.dynamics.centering
+            and self.dynamics.graph_type == 'FC' and not self.dynamics.centering and not self.dynamics.sin_embedding
 
     @torch.no_grad()
     def sample_chain(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames=None,

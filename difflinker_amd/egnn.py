@@ -107,8 +107,12 @@ class EGNN(_ParamOnly):
     """Embedding, ``n_layers`` EquivariantBlocks, output projection (egnn.py:181-216)."""
 
     def __init__(self, in_node_nf, hidden_nf, activation, n_layers, norm_constant, inv_sublayers,
-                 normalization_factor, aggregation_method, out_node_nf=None, attention=False, tanh=False, coords_range=15):
+                 normalization_factor, aggregation_method, out_node_nf=None, attention=False, tanh=False, coords_range=15,
+                 sin_embedding=False):
         super().__init__()
+        # SinusoidsEmbeddingNew (egnn.py:281-292) has no parameters: 6 frequencies x (sin, cos) for each of the two distances
+        self.sin_embedding = bool(sin_embedding)
+        edge_feat_nf = 24 if sin_embedding else 2               # egnn.py:193-198
         # the reference computes coords_range / n_layers here but hands the UNDIVIDED value to its blocks (egnn.py:192,213)
         self.coords_range_layer = float(coords_range / n_layers)
         out_node_nf = in_node_nf if out_node_nf is None else out_node_nf
@@ -120,7 +124,7 @@ class EGNN(_ParamOnly):
         self.embedding_out = nn.Linear(hidden_nf, out_node_nf)
         for i in range(n_layers):
             self.add_module(f'e_block_{i}', EquivariantBlock(
-                hidden_nf, edge_feat_nf=2, activation=activation, n_layers=inv_sublayers,
+                hidden_nf, edge_feat_nf=edge_feat_nf, activation=activation, n_layers=inv_sublayers,
                 norm_constant=norm_constant, normalization_factor=normalization_factor,
                 aggregation_method=aggregation_method, attention=attention, tanh=tanh, coords_range=coords_range))
 
@@ -171,8 +175,8 @@ class Dynamics(nn.Module):
             raise NotImplementedError(f"model={model!r}: the HIP path implements 'egnn_dynamics' only")
         unsupported = []
         # attention, tanh and aggregation_method='mean' run in every kernel family (round 3: the pocket / large-molecule kernels
-        # too); no released configuration uses any of them
-        if sin_embedding: unsupported.append('sin_embedding=True')
+        # too); sin_embedding=True runs on the HBM-resident per-pass kernels only (every molecule is routed there, the fused
+        # chain kernel is not used).  No released configuration uses any of them.
         if aggregation_method not in ('sum', 'mean'): unsupported.append(f'aggregation_method={aggregation_method!r}')
         if not isinstance(activation, nn.SiLU): unsupported.append(f'activation={activation!r}')
         if hidden_nf != 128: unsupported.append(f'hidden_nf={hidden_nf}')
@@ -193,13 +197,14 @@ class Dynamics(nn.Module):
         self.norm_constant = norm_constant
         self.normalization_factor = normalization_factor
         self.attention, self.tanh, self.aggregation_method = bool(attention), bool(tanh), aggregation_method
+        self.sin_embedding = bool(sin_embedding)
         # `normalization` (batch_norm in the YAMLs) is only forwarded to the GNN branch by the reference
         # (egnn.py:341-368): a no-op for egnn_dynamics, accepted and ignored here too.
         self.dynamics = EGNN(
             in_node_nf=in_node_nf + context_node_nf + int(condition_time), hidden_nf=hidden_nf,
             activation=activation, n_layers=n_layers, norm_constant=norm_constant, inv_sublayers=inv_sublayers,
             normalization_factor=normalization_factor, aggregation_method=aggregation_method, attention=attention,
-            tanh=tanh)
+            tanh=tanh, sin_embedding=sin_embedding)
         self.n_layers = n_layers
         self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
         self._hip_models = {}                          # device index -> (_HipModel, weight version)
@@ -234,7 +239,8 @@ class Dynamics(nn.Module):
                              condition_time=1, norm_constant=float(self.norm_constant),
                              normalization_factor=float(self.normalization_factor),
                              precision=_lib.PRECISIONS[self.precision], attention=int(self.attention), tanh=int(self.tanh),
-                             coords_range=15.0, aggregation_mean=int(self.aggregation_method == 'mean'), sin_embedding=0)
+                             coords_range=15.0, aggregation_mean=int(self.aggregation_method == 'mean'),
+                             sin_embedding=int(self.sin_embedding))
 
     def hip_model(self, device):
         """``dl_model`` handle for ``device`` (packs + uploads the weights on first use / after a change)."""
@@ -323,6 +329,9 @@ class Dynamics(nn.Module):
                     node_mask3=node_mask.reshape(bs, n_nodes, 1))
         if type(self) is not Dynamics:
             return prep
+        if self.sin_embedding:                                     # HBM-resident kernels for every molecule
+            prep['large'] = True
+            return prep
         small, med, big = self.size_classes(prep['nm'])
         if small is None and med is None and big is None:
             return prep
@@ -404,7 +413,7 @@ class Dynamics(nn.Module):
                                                        ctypes.c_void_p(stream)), 'dl_egnn_forward_fc_team')
             else:
                 if em is None:
-                    raise ValueError('molecules beyond the LDS-resident limit need the edge_mask tensor')
+                    raise ValueError('the HBM-resident kernels (molecules beyond the LDS-resident limit, sin_embedding) need edge_mask')
                 need = int(lib.dl_pocket_workspace_bytes(bs, n_nodes))
                 ws = getattr(self, '_large_ws', None)
                 if ws is None or ws.numel() < need or ws.device != dev:

@@ -77,8 +77,8 @@ typedef enum dl_status {
 typedef enum dl_precision { DL_PRECISION_FP32 = 0, DL_PRECISION_F16X3 = 1 } dl_precision;
 
 /* Dynamics.__init__ hyper-parameters (src/egnn.py:324-329).  The HIP path implements the
- * released-config surface: model='egnn_dynamics', SiLU, attention=False, tanh=False,
- * sin_embedding=False, aggregation_method='sum', hidden_nf=128, inv_sublayers=2. */
+ * released-config surface (model='egnn_dynamics', SiLU, hidden_nf=128, inv_sublayers=2) plus the optional attention, tanh,
+ * aggregation_method='mean' (every kernel family) and sin_embedding (HBM-resident kernels). */
 typedef struct dl_config {
     int32_t n_dims;               /* 3                                              */
     int32_t in_node_nf;           /* atom-type channels nf (8 ZINC, 9 GEOM/pockets) */
@@ -98,7 +98,9 @@ typedef struct dl_config {
     int32_t aggregation_mean;     /* 0: sum / normalization_factor; 1: / number of edges of the row, masked ones included
                                    * (= the padded width N on the fully-connected graph, the atom's degree on a radius
                                    * graph)                                                        src/egnn.py:315-319      */
-    int32_t sin_embedding;        /* must be 0 (src/egnn.py:281-292: not in the kernels)                                   */
+    int32_t sin_embedding;        /* 1: 24 sinusoidal edge attributes (src/egnn.py:281-292); the weights' edge-MLP input rows are
+                                   * then [128][280].  HBM-resident entry points only (dl_egnn_forward_fc_large,
+                                   * dl_egnn_forward_pocket); the LDS-resident ones answer DL_ERR_UNSUPPORTED               */
 } dl_config;
 
 typedef struct dl_model dl_model; /* opaque: packed, pre-scaled weights resident in HBM */

@@ -70,7 +70,7 @@ def test_team_knob_of_the_dynamics():
 
 def test_unsupported_hparams_raise():
     from difflinker_amd import Dynamics
-    for kw in (dict(sin_embedding=True), dict(aggregation_method='max'), dict(hidden_nf=64), dict(model='gnn_dynamics')):
+    for kw in (dict(aggregation_method='max'), dict(hidden_nf=64), dict(model='gnn_dynamics')):
         args = dict(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1)
         args.update(kw)
         with pytest.raises(NotImplementedError):
@@ -89,6 +89,16 @@ def test_optional_hparams_own_the_reference_parameters():
     assert len(order) == 4 + 2 * (2 * 10 + 5) and 'e_block_1.gcl_0.att_mlp.0.bias' in order
     cfg = dyn.hip_config()
     assert (cfg.attention, cfg.tanh, cfg.aggregation_mean, cfg.sin_embedding) == (1, 1, 1, 0) and cfg.coords_range == 15.0
+
+
+def test_sin_embedding_widens_the_edge_mlps():
+    """sin_embedding=True: 24 edge attributes instead of 2 (egnn.py:193-198), flagged in the C-ABI config."""
+    from difflinker_amd import Dynamics
+    dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=2, norm_constant=1e-6, sin_embedding=True)
+    expect = dynamics_param_shapes(11, 128, 2, edge_feat_nf=24)
+    assert [(k, tuple(v.shape)) for k, v in dyn.state_dict().items()] == [(e[0], tuple(e[1])) for e in expect]
+    assert dyn.state_dict()['dynamics.e_block_0.gcl_equiv.coord_mlp.0.weight'].shape == (128, 280)
+    assert dyn.hip_config().sin_embedding == 1
 
 
 def test_state_dict_keys_and_tensor_order():
