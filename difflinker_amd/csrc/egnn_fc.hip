@@ -226,14 +226,15 @@ __device__ __forceinline__ void store_row(const Lds& v, float* buf, int row, int
 }
 
 // f16x3 magnitude-bound slots in v.fmax (float bits of non-negative maxima)
-constexpr int FM_H0 = 0, FM_H1 = 1, FM_HG = 2, FM_AGG = 3, FM_X2B = 4, FM_X2 = 5, FM_X02 = 6;
+constexpr int FM_H0 = 0, FM_H1 = 1, FM_HG = 2, FM_AGG = 3, FM_XOWN = 4, FM_X2 = 5, FM_X02 = 6;
 // FM_H0/1: max |h| over the OWN atoms (two slots alternate); FM_HG: over the whole molecule (teams: from the exchange headers);
-// FM_X2 (teams: FM_X2 / FM_X2B alternate, TM_XSLOT names the current one): max |x|^2 over every atom; FM_X02: the same at forward entry
+// FM_X2: max |x|^2 over every atom (teams: from the exchange headers); FM_X02: the same at forward entry; FM_XOWN (teams): max |x|^2
+// over the OWN atoms, kept where their coordinates change (forward entry, coordinate update) and published in the exchange header
 
 // f16x3: common scale S1 of the rank-2 geometric term (r * wr' and d0 * wd' products in one accumulator); sc[6], sc[7] =
 // max |wr'|, max |wd'|.  The sender rows Q are stored times S1 (node_pre) and enter that MFMA as its C operand.
 template <bool TEAM>
-__device__ __forceinline__ int x2_slot(const Lds& v) { return TEAM ? v.misc[TM_XSLOT] : FM_X2; }
+__device__ __forceinline__ int x2_slot(const Lds&) { return FM_X2; }
 template <bool TEAM>
 __device__ __forceinline__ float geo_scale(const Lds& v, const float* __restrict__ sc) {
     const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
@@ -668,7 +669,23 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nown, int nb,
         src[k] = v.A + max(min(e >> 5, nown - 1), 0) * pl.g * PB_STRIDE + 4 * (e & 31);
         s[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int ch = 0; ch < pl.g; ++ch) {
+    // (four chunks per round: their 16 reads are in flight together, the additions keep the chunk order - a team member has up
+    // to 256 / n_own slots per atom, a chain of that many LDS latencies otherwise)
+    int ch = 0;
+#ifndef DL_V_SEQ_REDUCE
+    for (; ch + 4 <= pl.g; ch += 4) {
+        float4 p[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) p[u][k] = *reinterpret_cast<const float4*>(src[k] + (ch + u) * PB_STRIDE);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { s[k].x += p[u][k].x; s[k].y += p[u][k].y; s[k].z += p[u][k].z; s[k].w += p[u][k].w; }
+    }
+#endif
+    for (; ch < pl.g; ++ch) {
         float4 p[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) p[k] = *reinterpret_cast<const float4*>(src[k] + ch * PB_STRIDE);
@@ -994,7 +1011,6 @@ template <int PREC>
 __device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, const float* __restrict__ sc, bool first, int par) {
     const int S = v.misc[TM_S], rank = v.misc[TM_RANK], nown = v.misc[TM_NOWN];
     const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
-    const int cur = v.misc[TM_XSLOT], nxt = cur ^ (FM_X2 ^ FM_X2B);
     const __amdgpu_buffer_rsrc_t rows = team_rows(v);
     const int pbase = int(epoch & 1u) * (NQMAX * TX_ROW * 4);
     const int hbase = TEAM_X_BYTES + int(epoch & 1u) * (TEAM_MAX * 16);
@@ -1005,42 +1021,49 @@ __device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, c
         const u32x4 bits = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
         __builtin_amdgcn_raw_buffer_store_b128(bits, rows, pbase + (a * TX_ROW + 4 * q4) * 4, 0, 16);     // aux 16: sc1
     }
-    if (tid == 0) {
-        const u32x4 hdr = {v.fmax[FM_H0 + par], 0u, 0u, 0u};
+    if (tid == 0) {                                            // header: the bounds of the own atoms (complete since the last barrier)
+        const u32x4 hdr = {v.fmax[FM_H0 + par], v.fmax[FM_XOWN], 0u, 0u};
         __builtin_amdgcn_raw_buffer_store_b128(hdr, rows, hbase + rank * 16, 0, 16);
-        v.fmax[nxt] = 0u; v.fmax[FM_HG] = 0u;
     }
     team_sync(v, tid, epoch);              // (its first barrier also ends every read of the own rows in v.B)
-    // coordinates first: S1 needs the new bound
-    float n2 = 0.0f;
+    // ONE round trip: every wave reads the S headers (the bounds of the molecule = their maxima: no workgroup reduction, no
+    // barrier), waves 0-1 the coordinates, everybody its share of the sender rows - all requested before anything is waited for
+    // (every load unconditional, on a clamped index: a predicated load into a register array makes the compiler wait for each)
+    const int ln = tid & 63;
+    const u32x4 hdr = __builtin_amdgcn_raw_buffer_load_b128(rows, hbase + min(ln, S - 1) * 16, 0, 16);
+    const u32x4 xb = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + (min(tid, nb - 1) * TX_ROW + HID) * 4, 0, 16);
+    constexpr int NQ4 = 4;                 // 4 x 512 x 16 bytes: the sender rows of 64 atoms; the rest (bigger molecules) below
+    u32x4 qv[NQ4];
+#pragma unroll
+    for (int k = 0; k < NQ4; ++k) {
+        const int e = min(tid + THREADS * k, nb * 32 - 1);
+        qv[k] = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + ((e >> 5) * TX_ROW + 4 * (e & 31)) * 4, 0, 16);
+    }
+    const unsigned hb = wave_max_u32(ln < S ? hdr.x : 0u), x2b = wave_max_u32(ln < S ? hdr.y : 0u);
     if (tid < nb) {
-        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + (tid * TX_ROW + HID) * 4, 0, 16);
-        const float4 x = make_float4(__uint_as_float(bits.x), __uint_as_float(bits.y), __uint_as_float(bits.z), 0.0f);
+        const float4 x = make_float4(__uint_as_float(xb.x), __uint_as_float(xb.y), __uint_as_float(xb.z), 0.0f);
         *reinterpret_cast<float4*>(v.xs + 4 * tid) = x;
         if (first) *reinterpret_cast<float4*>(v.x0 + 4 * tid) = x;
-        n2 = x.x * x.x + x.y * x.y + x.z * x.z;
     }
-    if (tid < 128) {                                           // waves 0, 1: the atoms; one lane per member: its max |h|
-        unsigned hm = 0u;
-        if (tid < S) { const u32x4 hdr = __builtin_amdgcn_raw_buffer_load_b128(rows, hbase + tid * 16, 0, 16); hm = hdr.x; }
-        const unsigned b = wave_max_u32(__float_as_uint(n2)), hb = wave_max_u32(hm);
-        if ((tid & 63) == 0) {
-            lds_max_u32(&v.fmax[nxt], b);
-            if (first) lds_max_u32(&v.fmax[FM_X02], b);
-            if (tid == 0) lds_max_u32(&v.fmax[FM_HG], hb);
-        }
+    if (tid == 0) {                        // readers: after the caller's barrier
+        v.fmax[FM_X2] = x2b; v.fmax[FM_HG] = hb;
+        if (first) v.fmax[FM_X02] = x2b;
     }
-    lds_barrier();
-    if (tid == 0) v.misc[TM_XSLOT] = nxt;                      // readers: after the caller's barrier
     float S1 = 1.0f;
     if (PREC == 1) {
-        const float x2 = __uint_as_float(v.fmax[nxt]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float x2 = __uint_as_float(x2b), x02 = first ? x2 : __uint_as_float(v.fmax[FM_X02]);
         S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(sc, 6)), scale_for(4.0f * x02) * scale_for(cload(sc, 7)));
     }
-    for (int e = tid; e < nb * 32; e += THREADS) {
-        const int a = e >> 5, q4 = e & 31;
-        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + (a * TX_ROW + 4 * q4) * 4, 0, 16);
-        *reinterpret_cast<float4*>(v.B + a * LDH + 4 * q4) =
+#pragma unroll
+    for (int k = 0; k < NQ4; ++k) {
+        const int e = tid + THREADS * k;
+        if (e < nb * 32)
+            *reinterpret_cast<float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)) =
+                make_float4(__uint_as_float(qv[k].x) * S1, __uint_as_float(qv[k].y) * S1, __uint_as_float(qv[k].z) * S1, __uint_as_float(qv[k].w) * S1);
+    }
+    for (int e = tid + THREADS * NQ4; e < nb * 32; e += THREADS) {
+        const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(rows, pbase + ((e >> 5) * TX_ROW + 4 * (e & 31)) * 4, 0, 16);
+        *reinterpret_cast<float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)) =
             make_float4(__uint_as_float(bits.x) * S1, __uint_as_float(bits.y) * S1, __uint_as_float(bits.z) * S1, __uint_as_float(bits.w) * S1);
     }
 }
@@ -1274,6 +1297,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
     const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
     pair_reduce_equiv(v, nown, nb, tid, xscale);
+    if (TEAM && PREC == 1 && tid == 0) v.fmax[FM_XOWN] = 0u;
     lds_barrier();                         // partials read: P, Q, W2' regions are free
     stage_next(v, nx, w, tid);
     if constexpr (TEAM) {
@@ -1299,7 +1323,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
             n2 = fmaf(xn, xn, n2);
         }
     }
-    if (PREC == 1 && !TEAM) block_max(&v.fmax[FM_X2], n2, lane);       // (a team: from the next exchange, over every atom)
+    if (PREC == 1) block_max(&v.fmax[TEAM ? FM_XOWN : FM_X2], n2, lane);       // (a team: the own atoms; the exchange headers carry it)
     prof_event(pf, w, lane, 34);
     lds_barrier();
     prof_event(pf, w, lane, 10);
@@ -1325,7 +1349,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int npass = ctx_i(v, CX_NPASS);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; if (TEAM) v.misc[TM_XSLOT] = FM_X2; }
+    if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
     prof_event(pf, w, lane, 1);
     if (PREC == 1) {
         if (tid < 8) v.fmax[tid] = 0u;
@@ -1341,14 +1365,17 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         v.xs[4 * a + k] = xv;
         v.x0[4 * a + k] = xv;
     }
-    if (PREC == 1 && !TEAM) {
+    if (PREC == 1) {                           // max |x|^2 at entry (a team: of the own atoms, for its first exchange header)
         float n2 = 0.0f;
-        if (tid < nb) {
+        if (tid < nown) {
             const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
             n2 = x0 * x0 + x1 * x1 + x2 * x2;
         }
         const unsigned b = wave_max_u32(__float_as_uint(n2));
-        if (lane == 0) { lds_max_u32(&v.fmax[FM_X2], b); lds_max_u32(&v.fmax[FM_X02], b); }
+        if (lane == 0) {
+            if (TEAM) lds_max_u32(&v.fmax[FM_XOWN], b);
+            else { lds_max_u32(&v.fmax[FM_X2], b); lds_max_u32(&v.fmax[FM_X02], b); }
+        }
     }
     // embedding: h = We * [h_feat, t, context] + be   (egnn.py:396-407, :224) -> fp32 rows in v.B (and the HBM scratch)
     {

@@ -12,6 +12,6 @@ run() {  # name, bench args...
   for f in $(find /tmp/rp_$name -name '*kernel_stats.csv' 2>/dev/null); do cp $f $OUT/${name}_kernel_stats.csv; done
   rm -rf /tmp/rp_$name
 }
-run c4_pockets --config C4 --steps 1 --warmup 1 --no-cpu-baseline
+run c4_pockets --config C4 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary
 run c2_b64_teams --batch 64 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary
 ls -la $OUT
