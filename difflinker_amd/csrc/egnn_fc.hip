@@ -101,7 +101,7 @@ __device__ __forceinline__ Lds lds_view(float* base) {
 // block 0 logs (tag, s_memtime) pairs into buf[wave][event][2] (dl_set_profile_buffer).  Compiled out of the product
 // library: even a never-taken branch per phase keeps the buffer pointer and the event counter alive across the pair
 // loops, i.e. in scratch, and each of the ~110 sites per forward then pays a reload round trip.
-constexpr int PROF_MAX_EVENTS = 512;
+constexpr int PROF_MAX_EVENTS = 1024;
 struct Prof {
     unsigned long long* buf;
     int n;
@@ -808,8 +808,25 @@ __device__ __forceinline__ void team_sync(const Lds& v, int tid, unsigned epoch)
 // Per-workgroup HBM scratch `hs` (floats): h rows fp32 [NMAX][HID] (residual, output head), then T0 tiles [8][16][64].
 constexpr int HS_HF = 0;                      // (teams, molecules of more than 55 atoms) the h fragment rows across a coordinate pass
 constexpr int HS_T0 = NMAX * HID;
-constexpr int HS_HT = HS_T0 + 8 * 16 * 64;    // the h rows once more, as tiles in accumulator order (the residual of the node MLP)
-constexpr int HS_STRIDE = HS_HT + 8 * 16 * 64;
+constexpr int HS_HT = HS_T0 + 8 * 16 * 64;    // the h rows once more, as accumulator tiles (the residual of the node MLP)
+constexpr int HS_HO = HS_HT + 8 * 16 * 64;    // the final h for the output head: tiles [reg][lane] (32 consecutive features per row)
+constexpr int HS_STRIDE = HS_HO + 8 * 16 * 64;
+// T0 / HT tiles: element (reg, lane) of tile t at ((4 t + reg / 4) * 64 + lane) * 4 + reg % 4 - a lane moves its 16 accumulator
+// registers with four 16-byte accesses, each a fully coalesced 1 KB per wave (16 dword accesses cost four times the issue slots of
+// the vector-memory pipe, which is what the node phases wait for)
+__device__ __forceinline__ void tile_store16(float* tiles, int t, int lane, const float (&x)[16]) {
+    float4* p = reinterpret_cast<float4*>(tiles) + size_t(4 * t) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[64 * q] = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+__device__ __forceinline__ void tile_load16(const float* tiles, int t, int lane, float (&x)[16]) {
+    const float4* p = reinterpret_cast<const float4*>(tiles) + size_t(4 * t) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t4 = p[64 * q];
+        x[4 * q] = t4.x; x[4 * q + 1] = t4.y; x[4 * q + 2] = t4.z; x[4 * q + 3] = t4.w;
+    }
+}
 
 // Uniform scalars of the packed weights (scales, bounds) through the SCALAR cache: a vector load of them would queue behind
 // every fragment prefetch and LDS-DMA in flight (vector memory returns in order) - s_load does not.
@@ -948,13 +965,14 @@ __device__ __forceinline__ void load_pre2_u0(PreW2& pw, const NextPass& nx, int 
     if (nx.equiv) pw.u0 = load_bfrag(nx.base + (w < 4 ? E_W5A : E_W5B) + nt * (UNIT / 4), lane);
     else pw.u0 = load_bfrag(nx.base + (w < 4 ? G_W1A : G_W1B) + nt * (UNIT / 4), lane);
 }
-__device__ __forceinline__ void load_pre2_u1(PreW2& pw, const NextPass& nx, int w, int lane) {
-    if (nx.base == nullptr || nx.equiv) return;
+// (T0 of atom tile 1 is the upper wave half's: with at most 32 own atoms - a team member, a small molecule - it does not exist)
+__device__ __forceinline__ void load_pre2_u1(PreW2& pw, const NextPass& nx, int w, int lane, int nown) {
+    if (nx.base == nullptr || nx.equiv || (w >= 4 && nown <= 32)) return;
     pw.u1 = load_bfrag(nx.base + G_W3A + (w & 3) * (UNIT / 4), lane);
 }
-__device__ __forceinline__ void load_pre2(PreW2& pw, const NextPass& nx, int w, int lane) {
+__device__ __forceinline__ void load_pre2(PreW2& pw, const NextPass& nx, int w, int lane, int nown) {
     load_pre2_u0(pw, nx, w, lane);
-    load_pre2_u1(pw, nx, w, lane);
+    load_pre2_u1(pw, nx, w, lane, nown);
 }
 
 // P (waves 0-3) / Q (waves 4-7) of both atom tiles of the OWN atoms and, in a GCL, T0 of atom tile (wave half), from the h
@@ -995,9 +1013,10 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nown, int w, int lan
             store_row(v, dst, row, nown, 32 * nt + c, (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, bias));
         }
         if (t0) {
-            float* tp = hs + HS_T0 + (4 * mt + nt) * (16 * 64) + lane;
+            float t0v[16];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) tp[64 * reg] = (PREC == 0) ? acc3[reg] : fmaf(acc3[reg], inv3, bias3);
+            for (int reg = 0; reg < 16; ++reg) t0v[reg] = (PREC == 0) ? acc3[reg] : fmaf(acc3[reg], inv3, bias3);
+            tile_store16(hs + HS_T0, 4 * mt + nt, lane, t0v);
         }
     }
 }
@@ -1008,7 +1027,7 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nown, int w, int lan
 // exchange of a forward), max |x|^2 over the molecule in the OTHER bound slot (which becomes the current one), max |h| over
 // the molecule in FM_HG.  Ends with every LDS write done but NOT yet fenced by a barrier (the caller's follows).
 template <int PREC>
-__device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, const float* __restrict__ sc, bool first, int par) {
+__device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, const float* __restrict__ sc, bool first, int par, Prof& pf) {
     const int S = v.misc[TM_S], rank = v.misc[TM_RANK], nown = v.misc[TM_NOWN];
     const unsigned epoch = unsigned(v.misc[TM_EPOCH]);
     const __amdgpu_buffer_rsrc_t rows = team_rows(v);
@@ -1025,7 +1044,9 @@ __device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, c
         const u32x4 hdr = {v.fmax[FM_H0 + par], v.fmax[FM_XOWN], 0u, 0u};
         __builtin_amdgcn_raw_buffer_store_b128(hdr, rows, hbase + rank * 16, 0, 16);
     }
+    prof_event(pf, tid >> 6, tid & 63, 111);
     team_sync(v, tid, epoch);              // (its first barrier also ends every read of the own rows in v.B)
+    prof_event(pf, tid >> 6, tid & 63, 112);
     // ONE round trip: every wave reads the S headers (the bounds of the molecule = their maxima: no workgroup reduction, no
     // barrier), waves 0-1 the coordinates, everybody its share of the sender rows - all requested before anything is waited for
     // (every load unconditional, on a clamped index: a predicated load into a register array makes the compiler wait for each)
@@ -1082,8 +1103,9 @@ __device__ __forceinline__ void open_pass(const Lds& v, int nb, int nown, const 
     if (nx.equiv) pre_phase<PREC, false, TEAM>(v, nown, w, lane, pw, nx.base + E_VEC, sc, nullptr, s_hf);
     else pre_phase<PREC, true, TEAM>(v, nown, w, lane, pw, nx.base + G_VEC, sc, hs, s_hf);
     if constexpr (TEAM) {
+        prof_event(pf, w, lane, 110);
         lds_barrier();                     // own Q rows complete
-        team_exchange_q<PREC>(v, nb, q.tid, sc, next_pass == 0, par);
+        team_exchange_q<PREC>(v, nb, q.tid, sc, next_pass == 0, par, pf);
     }
     if (q.tid == 0) v.misc[CX_PASS] = next_pass;
     prof_event(pf, w, lane, 11);
@@ -1134,9 +1156,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     float b4 = 0.0f;
     if (active) {
         b3b = load_bfrag(g + G_W3B + nt * (UNIT / 4), lane);
-        const float* tp = hs + HS_T0 + (4 * mt + nt) * (16 * 64) + lane;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) t0r[reg] = tp[64 * reg];
+        tile_load16(hs + HS_T0, 4 * mt + nt, lane, t0r);
     }
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();                         // partial rows complete
@@ -1173,9 +1193,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         load_a<PREC>(a, v.C, arow, hh);
         // for layer 2, under layer 1: its fragments, the residual tile (written by this lane, a pass ago), the bias
         b4f = load_bfrag(g + G_W4 + nt * (UNIT / 4), lane);
-        const float* hp = hs + HS_HT + (4 * mt + nt) * (16 * 64) + lane;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) hold[reg] = hp[64 * reg];
+        tile_load16(hs + HS_HT, 4 * mt + nt, lane, hold);
         b4 = vecs[5 * HID + 32 * nt + c];
         __builtin_amdgcn_sched_barrier(0);
         floatx16 acc;
@@ -1213,7 +1231,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     // behind layer 2's matrix instructions (their operands have been read): the fragments the next pass opens with, then the
     // next pass's W2' image - requested in the order of use, landing under the epilogue and the barrier
 #ifndef DL_V_PRE_AFTER
-    load_pre2(pw, nx, w, lane);
+    load_pre2(pw, nx, w, lane, nown);
 #endif
 #if !defined(DL_V_DMA_AFTER) && !defined(DL_V_PRE_AFTER)
     stage_next(v, nx, w, tid);
@@ -1223,13 +1241,19 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         floatx16& acc = acc2;
         const float inv = inv2;
         float hm = 0.0f;
+        float hnew[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float hv = (PREC == 0) ? acc[reg] : fmaf(acc[reg], inv, hold[reg]);
             put_elem<PREC>(row < nown ? v.C + row * LDH : v.dummy, 32 * nt + c, hv, s_hn);
-            hs[HS_HT + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hv;
+            hnew[reg] = hv;
             hm = fmaxf(hm, row < nown ? fabsf(hv) : 0.0f);
+        }
+        tile_store16(hs + HS_HT, 4 * mt + nt, lane, hnew);
+        if (cx.pass + 2 >= ctx_i(v, CX_NPASS)) {                     // the last GCL of the forward: the copy the output head reads
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) hs[HS_HO + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hnew[reg];
         }
         if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
     }
@@ -1238,7 +1262,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         v.misc[CX_PAR] = par ^ 1;
     }
 #ifdef DL_V_PRE_AFTER
-    load_pre2(pw, nx, w, lane);
+    load_pre2(pw, nx, w, lane, nown);
 #endif
 #if defined(DL_V_DMA_AFTER) || defined(DL_V_PRE_AFTER)
     stage_next(v, nx, w, tid);
@@ -1291,7 +1315,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane;
     PreW2 pw;
-    load_pre2(pw, nx, w, lane);            // the fragments the next block opens with, under the reduction
+    load_pre2(pw, nx, w, lane, nown);            // the fragments the next block opens with, under the reduction
     __builtin_amdgcn_sched_barrier(0);
     lds_barrier();                         // partial triples complete
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
@@ -1403,9 +1427,9 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
                 acc = fmaf(wrow[k], hin, acc);
             }
             v.B[l * LDH + f] = acc;
-            {   // accumulator-order copy: row l of tile (l / 32, f / 32) sits in register (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1
+            {   // accumulator-tile copy (tile_store16's layout): row l of tile (l / 32, f / 32) sits in register (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1
                 const int r = l & 31;
-                hs[HS_HT + (((l >> 5) * 4 + (f >> 5)) * 16 + (r & 3) + 4 * (r >> 3)) * 64 + (f & 31) + 32 * ((r >> 2) & 1)] = acc;
+                hs[HS_HT + ((((l >> 5) * 4 + (f >> 5)) * 4 + (r >> 3)) * 64 + (f & 31) + 32 * ((r >> 2) & 1)) * 4 + (r & 3)] = acc;
             }
             hmax = fmaxf(hmax, fabsf(acc));
         }
@@ -1422,7 +1446,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     prof_event(pf, w, lane, 2);
     {
         PreW2 pw;
-        load_pre2(pw, first, w, lane);
+        load_pre2(pw, first, w, lane, nown);
         open_pass<PREC, TEAM>(v, nb, nown, first, hs, pf, pw, 0, 0);
     }
 #pragma nounroll
@@ -1453,7 +1477,7 @@ __device__ __forceinline__ void head_phase(const Lds& v) {
         const int a = e / nf, o = e - a * nf;
         // row a of the accumulator-order tiles: 32 consecutive floats per feature tile (k ascending: the reference's order)
         const int r = a & 31;
-        const float* hp = hs + HS_HT + ((a >> 5) * 4 * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1);
+        const float* hp = hs + HS_HO + ((a >> 5) * 4 * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1);
         const float* wo = wp + OFF_OUT_W + o * HID;
         float acc = wp[OFF_OUT_B + o];
 #pragma unroll

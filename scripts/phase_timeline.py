@@ -72,7 +72,8 @@ names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: b
          (32, 33): 'eq: PAIR loop + partials', (33, 34): 'eq: reduce + x', (34, 10): 'eq: end barrier', (34, 3): 'eq: end barrier',
          (2, 10): 'h->regs', (3, 4): 'output head', (14, 104): 'gcl: mlp1 frags+gemm(h)', (104, 105): 'gcl: mlp1 image DMA issue + gemm(agg)',
          (105, 15): 'gcl: mlp1 epilogue', (14, 105): 'gcl: mlp1 frags + both gemms', (15, 106): 'gcl: barrier + mlp2 residual loads', (106, 107): 'gcl: mlp2 gemm',
-         (107, 16): 'gcl: mlp2 epilogue (LDS + HBM rows)', (22, 23): 'gcl: W2\' DMA issue + agg fragment rows', (23, 14): 'gcl: barrier (agg in place)'}
+         (107, 16): 'gcl: mlp2 epilogue (LDS + HBM rows)', (10, 110): 'open: projections P, Q, T0', (110, 111): 'open: barrier + exchange stores',
+         (111, 112): 'open: team sync (drain, barrier, flags)', (112, 11): 'open: exchange loads -> LDS', (22, 23): 'gcl: W2\' DMA issue + agg fragment rows', (23, 14): 'gcl: barrier (agg in place)'}
 inloop = {(40, 41): 'L1 (geo, SiLU, split)', (41, 42): 'M0 (48 mfma)', (42, 43): 'E0 (epilogue)', (43, 44): 'M1 (48 mfma)',
           (44, 45): 'E1 (epilogue)'}
 for w in range(8):
