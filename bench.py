@@ -183,7 +183,7 @@ def secondary_measurements(device, a):
         t_k = (kms * 1e-3) if kms is not None else dt
         B = inp['x'].shape[0]
         out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}, noise={edm.noise_source}; {note}',
-                    'compute_units_per_molecule': None if pockets else (2 if config == 'C2L' else edm.dynamics.team_for(B)), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
+                    'compute_units_per_molecule': None if pockets else (max(2, edm.dynamics.team_for_size(B, device)) if config == 'C2L' else edm.dynamics.team_for(B)), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
                     'roofline_frac': flops / t_k / 1e12 / peak, 'roofline_peak_tflops': peak,
                     'achieved_tflops': flops / t_k / 1e12})
 
@@ -192,7 +192,7 @@ def secondary_measurements(device, a):
         '(2 x 502 randn launches per chain on the stream, a 308 MB bank in HBM) instead of the in-kernel draws', noise='torch')
     run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph')
     run('c5_shard', 'C5', None, 'f16x3', 'BASELINE config 5, one GPU\'s shard: the C4 molecules, batch 64, EDM built with timesteps = 1000, T = 1000')
-    run('c2_large_molecules', 'C2L', None, 'f16x3', '60..80 atoms per molecule: beyond one compute unit\'s LDS (55), fused chain on teams of two '
+    run('c2_large_molecules', 'C2L', None, 'f16x3', '60..80 atoms per molecule: beyond one compute unit\'s LDS (55), fused chain on teams of at least two '
         'compute units per molecule (each holds its own atoms\' state and every atom\'s sender row); round 2: HBM-resident kernels, host loop')
     run('c2_batch_64_one_cu_each', 'C2', 64, 'f16x3', 'the reference\'s default sampling batch (generate.py:145), one compute unit per '
         'molecule: a quarter of the chip', team=1)

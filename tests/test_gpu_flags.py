@@ -178,3 +178,14 @@ def test_options_on_teams_and_beyond():
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     ev, eh = P.report('flags on a 120-atom molecule (HBM-resident kernels)', P.run_hip_forward(dyn, inp, z, t), ref, z)
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+
+
+def test_sin_embedding_is_refused_by_the_lds_resident_entry_points():
+    """C ABI: dl_egnn_forward_fc_team / dl_sample_chain_fc answer DL_ERR_UNSUPPORTED for a sin_embedding model (no silent wrong
+    arithmetic); the Python layer never sends such a model there."""
+    from difflinker_amd import _lib
+    dyn, _, _ = make(9, 1, 1, 280, dict(sin_embedding=True), 'f16x3', 0.02)
+    inp, z, t = P.ragged_inputs([10, 8], [3, 2], 9, seed=281)
+    d = {k: v.to(P.dev()) for k, v in inp.items()}
+    with pytest.raises(_lib.HipLibraryError, match='dl_egnn_forward_fc_team'):
+        dyn._launch_forward(t.to(P.dev()), z.to(P.dev()), d['node_mask'], d['linker_mask'], d['edge_mask'], d['context'], large=False)

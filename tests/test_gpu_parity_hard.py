@@ -292,3 +292,62 @@ def test_split_fp16_is_fp32_class_against_the_fp64_oracle():
           f'vel abs-L2: fp32 {err["fp32"][1]:.3e}, f16x3 {err["f16x3"][1]:.3e}')
     assert err['f16x3'][0] <= 2.0 * err['fp32'][0]
     assert err['f16x3'][1] <= 2.0 * err['fp32'][1]
+
+
+def _overflowing_head_case(special_is_linker):
+    """One block whose coordinate head overflows for ONE receiving atom only: every GCL weight is zero (h stays the embedding),
+    the embedding gives atom type 7 - one atom of molecule 0 - the feature h[0] = 1e10, the head reads the receiver's h[0] and
+    multiplies it up to 1e42.  That receiver's sum of trans = coord_diff * inf holds inf and, from its own diagonal edge
+    (coord_diff = 0, edge mask 0), NaN (egnn.py:106-112)."""
+    nf = 9
+    inp, z, t = P.ragged_inputs([20, 12], [5, 4], nf, seed=300)
+    special = 17 if special_is_linker else 3                   # molecule 0: atoms 0..14 fragment, 15..19 linker
+    z[:, :, 3 + 7] = 0.0
+    z[0, special, 3 + 7] = 1.0
+    sd = seeded_state_dict(nf + 2, 128, 1, 301)
+    for v in sd.values():
+        v.zero_()
+    # (every single weight and intermediate stays below 1e22 - the range of the f16x3 scales, DESIGN 'limits' - only the head's
+    # last product, 1e10 * 1e32, leaves fp32)
+    sd['dynamics.embedding.weight'][0, 7] = 1e10
+    sd['dynamics.e_block_0.gcl_equiv.coord_mlp.0.weight'][0, 0] = 1e10
+    sd['dynamics.e_block_0.gcl_equiv.coord_mlp.2.weight'][0, 0] = 1e12
+    sd['dynamics.e_block_0.gcl_equiv.coord_mlp.4.weight'][0, 0] = 1e10
+    return inp, z, t, sd, EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=1), special
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+def test_overflow_in_a_linker_atoms_coordinate_sum_raises_like_the_reference(precision):
+    from difflinker_amd import Dynamics
+    from difflinker_amd.utils import FoundNaNException
+    inp, z, t, sd, cfg, _ = _overflowing_head_case(special_is_linker=True)
+    with pytest.raises(egnn_oracle.OracleNaN):
+        egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    dyn = Dynamics(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+    dyn.precision = precision
+    dyn.load_state_dict(sd, strict=True)
+    with pytest.raises(FoundNaNException) as info:
+        P.run_hip_forward(dyn.to(P.dev()), inp, z, t)
+    assert info.value.only_x_nan_idx == {0} and not info.value.x_h_nan_idx and not info.value.only_h_nan_idx    # molecule 0, coordinates (utils.py:283-289)
+
+
+@pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
+def test_overflow_confined_to_a_fragment_atoms_coordinate_sum_is_a_known_divergence(precision):
+    """The reference sums trans for EVERY receiving atom and multiplies the sum by the linker mask afterwards (egnn.py:110-116):
+    an inf / NaN in a fragment atom's sum becomes NaN * 0 = NaN in its coordinates and Dynamics.forward raises
+    FoundNaNException (egnn.py:441-442; generate.py:154-161 then re-samples the batch).  The HIP path never forms the sums the
+    mask discards (the coordinate pass runs over linker receivers only: DESIGN.md, coordinate pass), so a non-finite value that
+    exists ONLY there is not seen: the forward returns, finite everywhere, the fragment atom unmoved.  Pinned here so that the
+    difference is a decision on record and not an accident; anything non-finite that reaches a sum the mask keeps raises as
+    the reference does (previous test)."""
+    from difflinker_amd import Dynamics
+    inp, z, t, sd, cfg, special = _overflowing_head_case(special_is_linker=False)
+    with pytest.raises(egnn_oracle.OracleNaN):
+        egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    dyn = Dynamics(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+    dyn.precision = precision
+    dyn.load_state_dict(sd, strict=True)
+    out = P.run_hip_forward(dyn.to(P.dev()), inp, z, t)
+    assert bool(torch.isfinite(out).all())
+    assert float(out[0, special, :3].abs().max()) == 0.0          # velocity of the atom whose sum the reference poisons
+    assert float(out[..., :3].abs().max()) == 0.0                 # (every other receiver's head output is exactly 0 here)
