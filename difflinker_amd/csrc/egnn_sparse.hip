@@ -483,7 +483,11 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     const int nquads = w.total[0];
     const int ntiles = (nquads + 3) >> 2;
     const int qg = c >> 3;                                           // quad of this lane's slot
-    const int gw = blockIdx.x * (EDGE_THREADS / 64) + wv, GW = gridDim.x * (EDGE_THREADS / 64);
+    // XCD-aware tile walk: workgroup b runs on XCD b % 8 (each with its own L2); an XCD takes one contiguous eighth of the work
+    // list - the tiles of a few molecules - so that the sender rows it gathers (512 B per edge) stay in its L2 instead of
+    // every L2 seeing every molecule's rows
+    const int xcd = blockIdx.x & 7, nblk = (int(gridDim.x) + 7 - xcd) >> 3;
+    const int gw = (blockIdx.x >> 3) * (EDGE_THREADS / 64) + wv, GW = nblk * (EDGE_THREADS / 64);
     // receiving atom and sender of this lane's slot in tile tt (slots past the last quad: padding of the last atom)
     auto tile_atoms = [&](int tt, int& ii, int& jj) {
         const int qd = 4 * tt + qg;
@@ -502,9 +506,10 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     __shared__ __attribute__((aligned(16))) float Pst[EDGE_THREADS / 64][4 * LDT];   // row stride LDT: the four rows fall into different banks
     float* pst = Pst[wv];
     // work list: every tile (GCL), the tiles with a linker receiver (coordinate head)
-    const int nwork = EQUIV ? w.total[1] : ntiles;
     auto tile_of = [&](int k) { return EQUIV ? w.eq_tiles[k] : k; };
-    int idx = gw;
+    const int nall = EQUIV ? w.total[1] : ntiles;
+    const int wlo = int((long long)nall * xcd / 8), nwork = int((long long)nall * (xcd + 1) / 8);     // this XCD's part [wlo, nwork)
+    int idx = wlo + gw;
     int t = idx < nwork ? tile_of(idx) : 0;
     int i = 0, jraw = -1;
     float r = 0.0f, d0 = 0.0f, dx = 0.0f, dy = 0.0f, dz = 0.0f, pqb = 0.0f;
