@@ -672,7 +672,6 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nown, int nb,
     // (four chunks per round: their 16 reads are in flight together, the additions keep the chunk order - a team member has up
     // to 256 / n_own slots per atom, a chain of that many LDS latencies otherwise)
     int ch = 0;
-#ifndef DL_V_SEQ_REDUCE
     for (; ch + 4 <= pl.g; ch += 4) {
         float4 p[4][4];
 #pragma unroll
@@ -684,7 +683,6 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nown, int nb,
 #pragma unroll
             for (int k = 0; k < 4; ++k) { s[k].x += p[u][k].x; s[k].y += p[u][k].y; s[k].z += p[u][k].z; s[k].w += p[u][k].w; }
     }
-#endif
     for (; ch < pl.g; ++ch) {
         float4 p[4];
 #pragma unroll
@@ -1230,12 +1228,8 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     __builtin_amdgcn_sched_barrier(0);
     // behind layer 2's matrix instructions (their operands have been read): the fragments the next pass opens with, then the
     // next pass's W2' image - requested in the order of use, landing under the epilogue and the barrier
-#ifndef DL_V_PRE_AFTER
     load_pre2(pw, nx, w, lane, nown);
-#endif
-#if !defined(DL_V_DMA_AFTER) && !defined(DL_V_PRE_AFTER)
     stage_next(v, nx, w, tid);
-#endif
     __builtin_amdgcn_sched_barrier(0);
     if (active) {
         floatx16& acc = acc2;
@@ -1261,12 +1255,6 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         if (PREC == 1) v.fmax[FS_HS] = __float_as_uint(s_hn);
         v.misc[CX_PAR] = par ^ 1;
     }
-#ifdef DL_V_PRE_AFTER
-    load_pre2(pw, nx, w, lane, nown);
-#endif
-#if defined(DL_V_DMA_AFTER) || defined(DL_V_PRE_AFTER)
-    stage_next(v, nx, w, tid);
-#endif
     prof_event(pf, w, lane, 16);
     lds_barrier();
     if constexpr (TEAM) {
