@@ -28,6 +28,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL / tensor sharing fail with hipIpcGetMemHandle otherwise); the
+# driver exports it already - kept here so that a hand-started torchrun behaves the same
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch
 import torch.distributed as dist
 
