@@ -74,7 +74,7 @@ constexpr int TM_EPOCH = 2;      // exchanges completed so far
 constexpr int TM_FAIL = 3;       // a team-mate did not show up in time
 constexpr int TM_ROWS = 4;       // exchange rows of this molecule (device pointer: lo, hi)
 constexpr int TM_FLAGS = 6;      // arrival words of this molecule's workgroups (device pointer: lo, hi)
-constexpr int TM_S = 8, TM_RANK = 9, TM_NOWN = 10, TM_XSLOT = 11;   // team size, own index, number of own atoms (one workgroup: 1, 0, n_b), current max |x|^2 slot
+constexpr int TM_S = 8, TM_RANK = 9, TM_NOWN = 10;   // team size, own index, number of own atoms (one workgroup: 1, 0, n_b)
 constexpr int MS_NRCV = 12;      // (every kernel) length of the coordinate-pass receiver list v.rcv
 
 struct Lds {
@@ -234,10 +234,8 @@ constexpr int FM_H0 = 0, FM_H1 = 1, FM_HG = 2, FM_AGG = 3, FM_XOWN = 4, FM_X2 = 
 // f16x3: common scale S1 of the rank-2 geometric term (r * wr' and d0 * wd' products in one accumulator); sc[6], sc[7] =
 // max |wr'|, max |wd'|.  The sender rows Q are stored times S1 (node_pre) and enter that MFMA as its C operand.
 template <bool TEAM>
-__device__ __forceinline__ int x2_slot(const Lds&) { return FM_X2; }
-template <bool TEAM>
 __device__ __forceinline__ float geo_scale(const Lds& v, const float* __restrict__ sc) {
-    const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
+    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
     return fminf(scale_for(4.0f * x2) * scale_for(sc[6]), scale_for(4.0f * x02) * scale_for(sc[7]));
 }
 
@@ -1126,7 +1124,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);     // senders: any atom of the molecule
-        const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);            // >= |P_i| + |Q_j|
         sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
         accs = sa * cload(sc, 5);
@@ -1284,7 +1282,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     float sa = 1.0f, accs = 1.0f;
     if (PREC == 1) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
-        const float x2 = __uint_as_float(v.fmax[x2_slot<TEAM>(v)]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
         sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
         accs = sa * cload(sc, 2);
@@ -1569,7 +1567,6 @@ __device__ __forceinline__ void team_init(const Lds& v, int nb, int S, int rank,
     v.misc[TM_FLAGS] = int(unsigned(pf)); v.misc[TM_FLAGS + 1] = int(unsigned(pf >> 32));
     v.misc[TM_S] = S; v.misc[TM_RANK] = rank;
     v.misc[TM_NOWN] = nb > rank ? (nb - rank + S - 1) / S : 0;
-    v.misc[TM_XSLOT] = FM_X2;
 }
 
 __device__ __forceinline__ void ctx_store(const Lds& v, const ModelDims& md, int N, const int8_t* em, float* hs, const float* wp,
