@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void open_pass(const Lds& v, int nb, int nown, const 
 }
 
 // GCL (egnn.py:45-80), per-atom phases version 2; P, Q, T0 of this pass are in place (open_pass).  Ends with the next pass opened.
-template <int PREC, bool TEAM>
+template <int PREC, bool TEAM, bool ATT>
 __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     {   // ---- pair loop
     const PassCtx cx = pass_ctx(v);
@@ -1129,7 +1129,9 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
         accs = sa * cload(sc, 5);
     }
-    if (cx.flags & 1) pair_phase<false, PREC, true, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, cload(sc, 8), pf);
+    // (edge attention is a KERNEL variant, not a branch: its pair loop keeps the 64 messages of a step until the logit is known
+    // and spills ~80 registers, which would set the scratch size - and the register pressure around the call - of every launch)
+    if constexpr (ATT) pair_phase<false, PREC, true, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, cload(sc, 8), pf);
     else pair_phase<false, PREC, false, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
     prof_event(pf, w, lane, 13);
     }
@@ -1346,7 +1348,7 @@ __device__ __forceinline__ void head_phase(const Lds& v);
 // Dynamics.forward for the own atoms of the molecule resident in LDS: reads v.z (state), the linker mask v.lm, the context
 // words (CX_*: sizes, pointers, model flags, time feature; set by the kernel - CX_PASS / CX_PAR are reset here);
 // writes eps_hat[l][0:3+nf] of own atom l into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
-template <int PREC, bool TEAM>
+template <int PREC, bool TEAM, bool ATT>
 __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int tid = lane_ids().tid;
     const int nb = ctx_i(v, 0);
@@ -1438,7 +1440,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
 #pragma nounroll
     for (int p = 0; p < npass; p += 3) {
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) gcl_pass2<PREC, TEAM>(v, pf);
+        for (int gi = 0; gi < 2; ++gi) gcl_pass2<PREC, TEAM, ATT>(v, pf);
         equiv_pass2<PREC, TEAM>(v, pf);
     }
     prof_event(pf, w, lane, 3);
@@ -1581,7 +1583,7 @@ __device__ __forceinline__ void ctx_store(const Lds& v, const ModelDims& md, int
     v.misc[CX_TFEAT] = __float_as_int(tfeat); v.misc[CX_MOL] = mol;
 }
 
-template <int PREC, bool TEAM>
+template <int PREC, bool TEAM, bool ATT>
 __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
@@ -1629,7 +1631,7 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     Prof pf;
     pf.buf = (blockIdx.x == 0) ? p.prof : nullptr;
     pf.n = 0;
-    forward_molecule2<PREC, TEAM>(v, pf);
+    forward_molecule2<PREC, TEAM, ATT>(v, pf);
     {   // results of the own atoms (arguments and sizes re-read: see the pass context)
         const auto* P = kargs<FwdArgs>();
         const int tid = lane_ids().tid;
@@ -1661,7 +1663,7 @@ struct ChainArgs {
 
 // one reverse step (or the final decode, q == T) for the own atoms of the molecule in LDS: denoiser, then the sampler
 // algebra.  false: NaN, stop (one workgroup per molecule; a team goes on - its members must keep meeting - and only records it).
-template <int PREC, bool TEAM>
+template <int PREC, bool TEAM, bool ATT>
 __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     {
         const auto* P = kargs<ChainArgs>();
@@ -1675,7 +1677,7 @@ __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     Prof pf;
     pf.buf = (blockIdx.x == 0 && q == 0) ? kargs<ChainArgs>()->prof : nullptr;
     pf.n = 0;
-    forward_molecule2<PREC, TEAM>(v, pf);
+    forward_molecule2<PREC, TEAM, ATT>(v, pf);
     const auto* P = kargs<ChainArgs>();
     const int tid = lane_ids().tid;
     const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0);
@@ -1746,7 +1748,7 @@ __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     return true;
 }
 
-template <int PREC, bool TEAM>
+template <int PREC, bool TEAM, bool ATT>
 __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
@@ -1811,7 +1813,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     }
 #pragma nounroll
     for (int q = 0; q <= T; ++q)
-        if (!chain_step2<PREC, TEAM>(v, q)) return;
+        if (!chain_step2<PREC, TEAM, ATT>(v, q)) return;
     {   // frame 0: the final sample [x, one_hot(h)] of the own atoms
         const auto* P = kargs<ChainArgs>();
         const int tid = lane_ids().tid;
@@ -2271,15 +2273,18 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
     const int32_t rc = fc_workspace(B, team, workspace, workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
     a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
-    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
+    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3, att = m->cfg.attention != 0;
+    const void* kernel;
+    if (team <= 1) kernel = f16 ? (att ? (const void*)&egnn_forward_fc_kernel<1, false, true> : (const void*)&egnn_forward_fc_kernel<1, false, false>)
+                                : (att ? (const void*)&egnn_forward_fc_kernel<0, false, true> : (const void*)&egnn_forward_fc_kernel<0, false, false>);
+    else kernel = f16 ? (att ? (const void*)&egnn_forward_fc_kernel<1, true, true> : (const void*)&egnn_forward_fc_kernel<1, true, false>)
+                      : (att ? (const void*)&egnn_forward_fc_kernel<0, true, true> : (const void*)&egnn_forward_fc_kernel<0, true, false>);
     if (team <= 1) {
-        if (f16) hipLaunchKernelGGL((egnn_forward_fc_kernel<1, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((egnn_forward_fc_kernel<0, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+        void* params[] = {&a};
+        return hip_ok(hipLaunchKernel(kernel, dim3(ws.grid), dim3(THREADS), params, 0, st)) ? DL_OK : DL_ERR_HIP;
     }
     if (!hip_ok(hipMemsetAsync(nan_flags, 0, size_t(B) * sizeof(int32_t), st))) return DL_ERR_HIP;     // the members OR their bits in
-    const hipError_t e = f16 ? launch_team(reinterpret_cast<const void*>(&egnn_forward_fc_kernel<1, true>), ws.grid, st, &a)
-                             : launch_team(reinterpret_cast<const void*>(&egnn_forward_fc_kernel<0, true>), ws.grid, st, &a);
+    const hipError_t e = launch_team(kernel, ws.grid, st, &a);
     return hip_ok(e) ? DL_OK : DL_ERR_HIP;
 }
 
@@ -2307,17 +2312,20 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     const int32_t rc = fc_workspace(g->B, g->team, g->workspace, g->workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
     a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
-    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
+    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3, att = m->cfg.attention != 0;
+    const void* kernel;
+    if (g->team <= 1) kernel = f16 ? (att ? (const void*)&sample_chain_fc_kernel<1, false, true> : (const void*)&sample_chain_fc_kernel<1, false, false>)
+                                   : (att ? (const void*)&sample_chain_fc_kernel<0, false, true> : (const void*)&sample_chain_fc_kernel<0, false, false>);
+    else kernel = f16 ? (att ? (const void*)&sample_chain_fc_kernel<1, true, true> : (const void*)&sample_chain_fc_kernel<1, true, false>)
+                      : (att ? (const void*)&sample_chain_fc_kernel<0, true, true> : (const void*)&sample_chain_fc_kernel<0, true, false>);
     if (g->team <= 1) {
         a.a.team = 1;
-        if (f16) hipLaunchKernelGGL((sample_chain_fc_kernel<1, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((sample_chain_fc_kernel<0, false>), dim3(ws.grid), dim3(THREADS), 0, st, a);
-        return hip_ok(hipGetLastError()) ? DL_OK : DL_ERR_HIP;
+        void* params[] = {&a};
+        return hip_ok(hipLaunchKernel(kernel, dim3(ws.grid), dim3(THREADS), params, 0, st)) ? DL_OK : DL_ERR_HIP;
     }
     if (!hip_ok(hipMemsetAsync(g->nan_flags, 0, size_t(g->B) * sizeof(int32_t), st)) ||
         !hip_ok(hipMemsetAsync(g->nan_step, 0xFF, size_t(g->B) * sizeof(int32_t), st))) return DL_ERR_HIP;
-    const hipError_t e = f16 ? launch_team(reinterpret_cast<const void*>(&sample_chain_fc_kernel<1, true>), ws.grid, st, &a)
-                             : launch_team(reinterpret_cast<const void*>(&sample_chain_fc_kernel<0, true>), ws.grid, st, &a);
+    const hipError_t e = launch_team(kernel, ws.grid, st, &a);
     return hip_ok(e) ? DL_OK : DL_ERR_HIP;
 }
 
