@@ -2210,8 +2210,10 @@ size_t dl_workspace_bytes(int32_t B, int32_t team) {
 int32_t dl_team_max_atoms(int32_t team) { return team >= 2 ? NQMAX : NMAX; }
 
 // Largest team (1, 2, 4 or 8 workgroups per molecule) the current device holds for a batch of B with every workgroup
-// resident at once.  One compute unit in eight is left alone (a margin: the launch fails safe, but a co-tenant kernel on a
-// few compute units should not push the default path there).
+// resident at once (one workgroup per compute unit: LDS).  No margin is kept: the reference's default batch of 64 on teams of
+// four is exactly the chip, and halving that team for headroom would cost a third of its throughput every time, while the
+// rare co-tenant case is handled where it happens - the cooperative launch refuses a grid the device cannot hold, a team that
+// does not assemble fails together (flag bit 3) and the caller re-runs the batch on one compute unit per molecule.
 int32_t dl_team_max(int32_t B) {
     if (B <= 0) return 1;
     int dev = 0, cus = 0;
