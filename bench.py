@@ -1,7 +1,8 @@
 """bench.py — molecules/s of the full 500-step ``sample_chain`` (BASELINE.json metric) on N MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``)
+  (N > 1: launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...``; started without a
+   launcher, ``python bench.py --gpus N`` starts its N ranks itself the same way)
 
 A "step" is one complete ``EDM.sample_chain`` over one synthetic batch: T = 500 reverse steps + the
 final decode = 501 EGNN forwards, per GPU the workload of BASELINE config C2 (GEOM hparams, 6 blocks,
@@ -206,8 +207,26 @@ def secondary_measurements(device, a):
     return out
 
 
+def self_spawn(a):
+    """``python bench.py --gpus N`` started WITHOUT a launcher (the driver's command shape for N = 1): start the
+    N ranks ourselves through ``torch.distributed.run`` (one process per GPU, rendezvous on 127.0.0.1, a free port) and hand
+    their output through; rank 0 of the child job prints the one JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 1) // a.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_spawn(a))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -288,6 +307,12 @@ def main():
         k_avg_ms = sum(k_ms) / len(k_ms)
     else:                                                  # pocket path: many launches per chain
         k_avg_ms = 1e3 * elapsed / a.steps
+    per_rank = None
+    if world > 1:                                          # after the timed region: every rank's kernel time and all-gather time
+        from difflinker_amd.distributed import last_gather_ms
+        mine = {'rank': rank, 'kernel_ms': k_avg_ms, 'all_gather_ms': last_gather_ms(), 'molecules': B}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         achieved = flops_fwd * (cfg['T'] + 1) / (k_avg_ms * 1e-3) / 1e12
@@ -343,6 +368,7 @@ def main():
                                                  'of a block / the same kernel time'},
                          # kept for continuity with rounds 1-2, whose lines carried the executed figures under this key
                          'executed': {'achieved': executed, 'frac': executed / peak, 'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1)}},
+            'per_rank': per_rank,
             'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
                           'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '

@@ -7,6 +7,8 @@ One process per GPU (``torch.distributed``); rank r takes a contiguous slice of 
 batch.  Noise comes from the in-kernel counter-based generator keyed by the GLOBAL molecule index
 (or from an explicit global bank, sliced), so the sample of molecule b does not depend on the world size.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -56,12 +58,36 @@ def all_gather_frames(local_chain, batch_size, group=None):
     # RCCL ('nccl') gathers device tensors in place; gloo (several ranks on ONE GPU: functional checks on a single-GPU box)
     # has no device all-gather - the frames take the detour through host memory there
     via_host = send.is_cuda and dist.get_backend(group) == 'gloo'
+    timed = send.is_cuda and not via_host
+    if timed:                                 # the collective's duration on the stream, for bench.py (read later: no sync here)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    else:
+        t0 = time.perf_counter()
     if via_host:
         send = send.cpu()
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send.contiguous(), group=group)
     out = torch.cat([recv[r][:, :sizes[r][1] - sizes[r][0]] for r in range(world)], dim=1)
-    return out.to(local_chain.device) if via_host else out
+    out = out.to(local_chain.device) if via_host else out
+    if timed:
+        ev[1].record()
+        LAST_GATHER['events'], LAST_GATHER['host_s'] = ev, None
+    else:
+        LAST_GATHER['events'], LAST_GATHER['host_s'] = None, time.perf_counter() - t0
+    return out
+
+
+# duration of the most recent all_gather_frames of this process: a pair of stream events (RCCL) or host seconds (gloo)
+LAST_GATHER = {'events': None, 'host_s': None}
+
+
+def last_gather_ms():
+    if LAST_GATHER['events'] is not None:
+        s, e = LAST_GATHER['events']
+        e.synchronize()
+        return s.elapsed_time(e)
+    return None if LAST_GATHER['host_s'] is None else 1e3 * LAST_GATHER['host_s']
 
 
 def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=None, gather=True):
