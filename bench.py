@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4', 'C5', 'C2L'])
+    ap.add_argument('--config', default='C2', choices=['C1', 'C2', 'C4', 'C5', 'C2L', 'C2XL'])
     ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the config\'s)')
     ap.add_argument('--T', type=int, default=None, help='reverse steps (default: the config\'s, 500 for C2)')
     ap.add_argument('--uniform-size', action='store_true', help='unpadded variant: every molecule has N atoms')
@@ -65,7 +65,7 @@ def parse():
     ap.add_argument('--cpu-forwards', type=int, default=2)
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary measurements (exact-fp32 mode, C4 pockets, other batch sizes) of the N=1 line')
-    ap.add_argument('--precision', default=None, choices=['f16x3', 'fp32'], help='arithmetic mode (default: f16x3)')
+    ap.add_argument('--precision', default=None, choices=['f16x3', 'fp32', 'f16x2'], help='arithmetic mode (default: f16x3)')
     return ap.parse_args()
 
 
@@ -74,7 +74,8 @@ def build_model(cfg, device):
     torch.manual_seed(0)                                   # random-init weights of the named architecture
     cls = Dynamics if cfg['graph_type'] == 'FC' else DynamicsWithPockets
     dyn = cls(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128,
-              n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm', graph_type=cfg['graph_type'])
+              n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm', graph_type=cfg['graph_type'],
+              sin_embedding=bool(cfg.get('sin_embedding', False)))
     edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=cfg.get('timesteps', 500), noise_schedule='polynomial_2',
               noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
     edm.T = cfg['T']
@@ -163,13 +164,16 @@ def time_chains(edm, inp, steps=1, warmup=1):
 def secondary_measurements(device, a):
     """Driver-timed companions of the headline: the exact-fp32 arithmetic mode on the same C2 batch, the
     pocket configuration C4, and C2 at batch sizes off the one-molecule-per-compute-unit sweet spot.  One warm-up chain
-    and one timed chain each (a chain is 501 forwards: the timing noise is well below 1 %)."""
+    and one timed chain each (a chain is 501 forwards: the timing noise is well below 1 %).  Every line carries the fraction of
+    its ceiling on the reference algorithm's flop count (``roofline_frac``, SURVEY 8d F_min) AND on the work the kernels execute
+    (``executed_frac``: the coordinate head only for receiving atoms inside the linker mask) - VERDICT round 3."""
     from difflinker_amd import synthetic
     out = []
 
-    def run(tag, config, batch, precision, note, team='auto', noise=None):
+    def run(tag, config, batch, precision, note, team='auto', noise=None, sin_embedding=False):
         data, cfg = synthetic.make_batch(config, seed=1000, batch=batch)
         cfg['precision'] = precision
+        cfg['sin_embedding'] = sin_embedding
         pockets = cfg['graph_type'] != 'FC'
         inp_cpu = synthetic.sampler_inputs(data, pockets=pockets)
         inp = {k: v.to(device) for k, v in inp_cpu.items()}
@@ -181,30 +185,75 @@ def secondary_measurements(device, a):
         torch.manual_seed(4321)
         dt, kms = time_chains(edm, inp)
         pairs, nodes = synthetic.pair_and_node_counts(data)
+        pairs_coord = synthetic.coord_pair_count(data)
         if pockets:
-            pairs, _ = pocket_edge_count(inp_cpu)
-        flops = synthetic.flops_min(128, cfg['n_layers'], cfg['nf'] + cfg['ctx'] + 1, pairs, nodes) * (cfg['T'] + 1)
-        peak = FP32_MFMA_PEAK_TFLOPS if precision == 'fp32' else F16_MFMA_PEAK_TFLOPS / 3.0
+            pairs, pairs_coord = pocket_edge_count(inp_cpu)
+        fin = cfg['nf'] + cfg['ctx'] + 1
+        flops = synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes) * (cfg['T'] + 1)
+        flops_exec = synthetic.flops_executed(128, cfg['n_layers'], fin, pairs, pairs_coord, nodes) * (cfg['T'] + 1)
+        terms = synthetic.split_terms(precision, 128, cfg['n_layers'], fin, pairs, pairs_coord, nodes)
+        peak = FP32_MFMA_PEAK_TFLOPS if precision == 'fp32' else F16_MFMA_PEAK_TFLOPS / terms
         t_k = (kms * 1e-3) if kms is not None else dt
         B = inp['x'].shape[0]
+        fused = (not pockets) and kms is not None
         out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}, noise={edm.noise_source}; {note}',
-                    'compute_units_per_molecule': None if pockets else (max(2, edm.dynamics.team_for_size(B, device)) if config == 'C2L' else edm.dynamics.team_for(B)), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
-                    'roofline_frac': flops / t_k / 1e12 / peak, 'roofline_peak_tflops': peak,
-                    'achieved_tflops': flops / t_k / 1e12})
+                    'compute_units_per_molecule': None if (pockets or not fused) else (max(2, edm.dynamics.team_for_size(B, device)) if config == 'C2L' else edm.dynamics.team_for(B)), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
+                    'roofline_frac': flops / t_k / 1e12 / peak, 'executed_frac': flops_exec / t_k / 1e12 / peak,
+                    'roofline_peak_tflops': peak, 'achieved_tflops': flops / t_k / 1e12, 'executed_tflops': flops_exec / t_k / 1e12})
 
+    run('c2_f16x2', 'C2', None, 'f16x2', 'the headline batch in the opt-in two-term arithmetic of the GCL edge models (Dynamics.precision = \'f16x2\': '
+        'node features 3..9e-6 rel-L2 per forward against the fp32 oracle instead of 2..5e-7, coordinates unchanged; DESIGN.md)')
     run('c2_fp32_mode', 'C2', None, 'fp32', 'exact fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32), same batch as the headline')
     run('c2_torch_noise', 'C2', None, 'f16x3', "the headline batch with the reference's torch.randn call sequence as the noise source "
         '(2 x 502 randn launches per chain on the stream, a 308 MB bank in HBM) instead of the in-kernel draws', noise='torch')
     run('c4_pockets', 'C4', None, 'f16x3', 'pockets_difflinker_full_no_anchors_fc, N=292, FC-10A-4A radius graph')
+    run('c4_pockets_f16x2', 'C4', None, 'f16x2', 'C4 in the opt-in two-term arithmetic')
     run('c5_shard', 'C5', None, 'f16x3', 'BASELINE config 5, one GPU\'s shard: the C4 molecules, batch 64, EDM built with timesteps = 1000, T = 1000')
     run('c2_large_molecules', 'C2L', None, 'f16x3', '60..80 atoms per molecule: beyond one compute unit\'s LDS (55), fused chain on teams of at least two '
         'compute units per molecule (each holds its own atoms\' state and every atom\'s sender row); round 2: HBM-resident kernels, host loop')
+    run('c2_xl_molecules_host_loop', 'C2XL', None, 'f16x3', '120..150 atoms per molecule: beyond the fused paths (110), HBM-resident per-pass kernels '
+        '(dl_egnn_forward_fc_large) under the host-driven 501-step loop')
+    run('c2_sin_embedding_host_loop', 'C2', 64, 'f16x3', 'a sin_embedding model (egnn.py:281-292; no released configuration): every molecule on the '
+        'HBM-resident kernels under the host-driven loop', sin_embedding=True)
     run('c2_batch_64_one_cu_each', 'C2', 64, 'f16x3', 'the reference\'s default sampling batch (generate.py:145), one compute unit per '
         'molecule: a quarter of the chip', team=1)
     for b in (64, 128, 257, 512):
         run(f'c2_batch_{b}', 'C2', b, 'f16x3', 'Dynamics.team = auto: 4 / 2 compute units per molecule while the batch leaves the chip '
             'room (atoms dealt round-robin, per-atom phases split, sender rows exchanged through HBM once per pass), else one, biggest first')
     return out
+
+
+def eager_rocm_baseline(edm, cfg, inp_cpu, device, n_forwards=3):
+    """The reference path as plain PyTorch on THIS GPU (ROCm eager, fp32): the oracle port (``oracle/egnn_oracle.py``, the
+    reference's op sequence: edge list, gather, cat, linear, SiLU, scatter-add) moved to ``cuda:0`` - what a user of the
+    reference gets on an MI355X without this library (SURVEY 8d lists it as the optional second baseline).  A few forwards of
+    the whole batch after one warm-up, scaled to the T + 1 forwards of a chain; a baseline, never the product path."""
+    from oracle import egnn_oracle
+    pockets = cfg['graph_type'] != 'FC'
+    sd = {k: v.detach().to(device).clone() for k, v in edm.dynamics.state_dict().items()}
+    ocfg = egnn_oracle.EGNNConfig(in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], n_layers=cfg['n_layers'],
+                                  graph_type=cfg['graph_type'])
+    forward = egnn_oracle.dynamics_forward_pockets if pockets else egnn_oracle.dynamics_forward
+    B, N = inp_cpu['x'].shape[:2]
+    g = torch.Generator().manual_seed(1)
+    z = torch.cat([inp_cpu['x'], inp_cpu['h']], dim=2) * inp_cpu['fragment_mask'] + \
+        torch.randn((B, N, 3 + cfg['nf']), generator=g) * inp_cpu['linker_mask']
+    t = torch.full((B, 1), 0.5)
+    args = [sd, ocfg] + [v.to(device) for v in (t, z, inp_cpu['node_mask'], inp_cpu['linker_mask'], inp_cpu['edge_mask'],
+                                                  inp_cpu['context'])]
+    with torch.no_grad():
+        forward(*args)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_forwards):
+            forward(*args)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_forwards
+    chain_s = dt * (cfg['T'] + 1)
+    return {'value': B / chain_s, 'unit': 'molecules/s', 'kind': 'port', 'device': torch.cuda.get_device_name(device),
+            'sample': f'{n_forwards} Dynamics.forward calls of the oracle port (plain PyTorch fp32, ROCm eager) on the whole batch of {B} after '
+                      f'1 warm-up: {1e3 * dt:.1f} ms each; scaled x{cfg["T"] + 1} to the chain (every step costs the same; the sampler '
+                      f'algebra of a step is not counted)', 'ms_per_forward': 1e3 * dt}
 
 
 def self_spawn(a):
@@ -320,12 +369,14 @@ def main():
         layer_bytes = synthetic.layer_bytes(nodes, pairs)
         t_layer = k_avg_ms * 1e-3 / ((cfg['T'] + 1) * cfg['n_layers'])
         precision = edm.dynamics.precision
-        if precision == 'f16x3':
+        if precision in ('f16x3', 'f16x2'):
             # the 128-wide contractions run as 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate): the
-            # ALGORITHMIC-flop ceiling of the scheme is the dense f16 MFMA peak / 3
-            peak, peak_note = F16_MFMA_PEAK_TFLOPS / 3.0, \
-                'dense f16 MFMA peak 2500 TFLOP/s / 3 split terms (fp32-equivalent result); the pair loop is issue-bound on ' \
-                'VALU (2 SiLU per pair and channel + fp16 splits) + matrix time, see DESIGN.md'
+            # ALGORITHMIC-flop ceiling of the scheme is the dense f16 MFMA peak / 3 (f16x2: 2 terms in the GCL edge models'
+            # second layer, 3 elsewhere - the average over the executed work, synthetic.split_terms)
+            terms = synthetic.split_terms(precision, 128, cfg['n_layers'], fin, pairs, pairs_coord, nodes)
+            peak, peak_note = F16_MFMA_PEAK_TFLOPS / terms, \
+                f'dense f16 MFMA peak 2500 TFLOP/s / {terms:.2f} split terms per multiply-accumulate; the pair loop is bound by the ' \
+                'issue port its VALU, transcendental and matrix instructions share (profiles/r04), see DESIGN.md'
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
         # fabric-side bytes per launch: NOT measured in this run (rocprofv3 --pmc passes cannot run inside the timed
@@ -376,8 +427,15 @@ def main():
         }
         if world == 1 and not a.no_secondary and a.config == 'C2' and not a.uniform_size and a.batch is None and a.T is None:
             out['secondary'] = secondary_measurements(device, a)
+            # the library's default noise source is the reference's torch.randn call sequence (EDM.noise_source = 'torch'): its
+            # figure sits at the top level beside `value`, which is measured with the in-kernel draws at every --gpus
+            tn = [x for x in out['secondary'] if x['tag'] == 'c2_torch_noise']
+            if tn:
+                out['value_by_noise_source'] = {'philox (in-kernel, this line)': out['value'],
+                                                'torch (reference randn stream, library default)': tn[0]['molecules_per_s']}
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(edm, cfg, inp_cpu, a.cpu_forwards)
+            out['eager_rocm_baseline'] = eager_rocm_baseline(edm, cfg, inp_cpu, device)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get('DIFFLINKER_HIP_LIB') or os.path.join(_HERE, 'libdiffl
 
 DL_OK = 0
 ABI_VERSION = 6
-PRECISIONS = {'fp32': 0, 'f16x3': 1}
+PRECISIONS = {'fp32': 0, 'f16x3': 1, 'f16x2': 2}
 DL_ERR_TOO_MANY_ATOMS = -3
 
 

@@ -33,6 +33,7 @@
 #include "../../include/difflinker_hip.h"
 #include "pack_layout.h"
 
+
 namespace {
 
 constexpr int LDH = 132;            // LDS row stride of [n,128] fp32 tiles: 528 B = 33 x 16 B (conflict-free b128)
@@ -62,7 +63,8 @@ constexpr int L_MISC = L_RPOS + 56;                   // ints: [0] n_b, [1] nan 
 constexpr int MISC_WORDS = 40;
 constexpr int L_FMAX = L_MISC + MISC_WORDS;           // f16x3 magnitude bounds (float bits, atomicMax)
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_own (branch-free)
-constexpr int L_TOTAL = L_DUMMY + LDH;
+constexpr int L_PROG = L_DUMMY + LDH;                 // pair-loop progress of the 8 waves (fair sharing of a SIMD between its two waves)
+constexpr int L_TOTAL = L_PROG + 8;
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -354,6 +356,12 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             return (jn > 0) ? int(mrow[v.idx[min(jj, nb - 1)]]) : 0;       // steps past the range: see `ok` at the uses
         };
         int m_next = load_mask(0);
+        // The SIMD arbitrates VALU / MFMA issue between its two waves by priority, then AGE: with equal priorities waves 0-3 run a
+        // step in ~8.1 K ticks beside waves 4-7 (~14 K), leave the loop after 65 % of a pass and wait at the barrier while their
+        // partners finish alone - one wave per SIMD, at half the machine's rate (profiles/r04/wave_timeline.log).  Each wave
+        // publishes its step count and, at every step, takes the higher priority when it is not ahead of its partner.
+        int* prog = reinterpret_cast<int*>(v.A - L_A + L_PROG);
+        if (lane == 0) prog[w] = 0;
 
         for (int t = 0; t < q; ++t) {
             // the P row, the bias vectors and all of W2' do not depend on t: without an opaque offset the compiler hoists
@@ -363,6 +371,14 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             const float* Pp = Pp_ + opq;
             const float* bias_p = bias_p_ + opq;
             const float* w7_p = w7_p_ + opq;
+            loop_event(pf, w, lane, 50);
+            {
+                if (lane == 0) prog[w] = t;
+                const int other = __builtin_amdgcn_readfirstlane(prog[w ^ 4]);
+                const bool behind = (w >= 4) ? (t <= other) : (t < other);          // a tie goes to the younger wave (age favours the older)
+                if (behind) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             const bool ok = t < jn;
             const int j = ok ? j0 + t : 0;
             const int m_raw = m_next;
@@ -408,17 +424,13 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     for (int k = 0; k < 4; ++k) {
                         const int reg = 4 * qq + k;
                         const float y2 = (PREC == 0) ? c2[reg] : fmaf(c2[reg], inv_scale, bb[k]);
-                        if (PREC == 1 && !EQUIV && !ATT) {
+                        if (PREC != 0 && !EQUIV && !ATT) {
                             // m * y2 / (1 + 2^y2) with the multiplier inside the reciprocal: im = 1 / m (collate's edge_mask holds
                             // -1 and, on the diagonal, -2: exact), 2^100 for m = 0 (the term is < 2^-100 |y2|: nothing in fp32 sums)
                             agg[mt][reg] = fmaf(y2, __builtin_amdgcn_rcpf(fmaf(__builtin_amdgcn_exp2f(y2), im, im)), agg[mt][reg]);
                             continue;
                         }
-#if defined(DL_KO_TRANS)
-                        const float u2 = y2 * fmaf(y2, 0.25f, 0.5f);
-#else
                         const float u2 = silu_u(y2);
-#endif
                         if (EQUIV || ATT) ssum = fmaf(ww[k], u2, ssum);
                         if (ATT) c2[reg] = u2;                       // the message waits for its attention weight
                         else if (!EQUIV) agg[mt][reg] = fmaf(m, u2, agg[mt][reg]);
@@ -494,6 +506,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 // the three VALU chunks of each element pair of slab s+1; sched_barrier after every chunk pins the order.
                 // Only slab 0 is produced without MFMAs beside it and only slab 7's MFMAs have no VALU beside them.
                 // Fragments are double-buffered (2 x 8 registers), W2' fragments and P/Q rows arrive one group ahead.
+                constexpr bool TWO = (PREC == 2) && !EQUIV && !ATT;
                 const float xv = (hh ? d0 : r) * sX;
                 const float xh_ = __uint_as_float(__float_as_uint(xv) & 0xffffe000u);
                 const uint4 xf = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xh_, xh_)),
@@ -513,15 +526,10 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     const float4 t4 = *reinterpret_cast<const float4*>(Qp + 32 * mt + 8 * qq);
                     Qc[4 * qq] = t4.x; Qc[4 * qq + 1] = t4.y; Qc[4 * qq + 2] = t4.z; Qc[4 * qq + 3] = t4.w;
                 };
-                // (DL_KO_*: knock-out switches of the energy / timing experiments under profiles/; never set in the product build)
                 auto load_a = [&](int slab, int oh) {
                     const int buf = oh;
-#ifdef DL_KO_WREAD
-                    af[buf][0] = fh[0]; af[buf][1] = fl[0]; af[buf][2] = fh[1]; af[buf][3] = fl[1];
-#else
                     af[buf][0] = Wq[(slab * 4 + 2 * oh) * 64]; af[buf][1] = Wq[(slab * 4 + 2 * oh + 1) * 64];
                     af[buf][2] = Wq[((8 + slab) * 4 + 2 * oh) * 64]; af[buf][3] = Wq[((8 + slab) * 4 + 2 * oh + 1) * 64];
-#endif
                 };
                 // the three VALU chunks of element pair ge = 8 * tile + e (registers 2e, 2e+1 of the tile's accumulator)
                 auto chunk_a = [&](int ge) {
@@ -529,30 +537,31 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     const float4 P = Pq[gq & 1];
                     const float p0 = (e & 1) ? P.z : P.x, p1 = (e & 1) ? P.w : P.y;
                     yy[0] = fmaf(g1[2 * e], invS1, p0); yy[1] = fmaf(g1[2 * e + 1], invS1, p1);
-#ifdef DL_KO_TRANS
-                    ee[0] = yy[0] * 0.25f; ee[1] = yy[1] * 0.25f;
-#else
                     ee[0] = __builtin_amdgcn_exp2f(yy[0]); ee[1] = __builtin_amdgcn_exp2f(yy[1]);
-#endif
                 };
                 auto chunk_b = [&]() {
                     // SiLU in u-form, scaled into the fp16 range: y * sa / (1 + 2^y)
-#ifdef DL_KO_TRANS
-                    ee[0] = fmaf(ee[0], isa, isa) * 0.5f; ee[1] = fmaf(ee[1], isa, isa) * 0.5f;
-#else
                     ee[0] = __builtin_amdgcn_rcpf(fmaf(ee[0], isa, isa)); ee[1] = __builtin_amdgcn_rcpf(fmaf(ee[1], isa, isa));
-#endif
                 };
                 auto chunk_c = [&](int ge) {
                     uu[0] = yy[0] * ee[0]; uu[1] = yy[1] * ee[1];
-#ifdef DL_KO_SPLIT
-                    const unsigned hp = __float_as_uint(uu[0]) & 0x3bff3bffu, lp = __float_as_uint(uu[1]) & 0x3bff3bffu;
-#else
+                    if constexpr (TWO) {
+                        // activation rounded to nearest fp16 (v_cvt_pk_f16_f32), no lo part: a_rn * (W_hi + W_lo)
+                        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                        typedef float float2v __attribute__((ext_vector_type(2)));
+                        const float2v u2 = {uu[0], uu[1]};
+                        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(u2, half2v));
+                        const int buf = (ge >> 2) & 1, d = ge & 3;
+                        if (d == 0) fh[buf].x = hp;
+                        if (d == 1) fh[buf].y = hp;
+                        if (d == 2) fh[buf].z = hp;
+                        if (d == 3) fh[buf].w = hp;
+                        return;
+                    }
                     const float h0 = __uint_as_float(__float_as_uint(uu[0]) & 0xffffe000u);
                     const float h1 = __uint_as_float(__float_as_uint(uu[1]) & 0xffffe000u);
                     const unsigned hp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
                     const unsigned lp = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(uu[0] - h0, uu[1] - h1));
-#endif
                     const int buf = (ge >> 2) & 1, d = ge & 3;      // slab parity, dword of the fragment
                     if (d == 0) { fh[buf].x = hp; fl[buf].x = lp; }
                     if (d == 1) { fh[buf].y = hp; fl[buf].y = lp; }
@@ -564,11 +573,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     const int oh = i / 6, m6 = i % 6;
                     const uint4& a = af[oh][(m6 < 2 ? 2 : 0) + (m6 & 1)];          // lo, lo, hi, hi, hi, hi
                     const uint4& b = (m6 == 2 || m6 == 3) ? fl[s & 1] : fh[s & 1];
-#ifdef DL_KO_MFMA2
-                    c2[2 * oh + (m6 & 1)][i & 15] += __uint_as_float((a.x ^ b.y) & 0x3fffffffu);
-#else
                     c2[2 * oh + (m6 & 1)] = mfma_h(a, b, c2[2 * oh + (m6 & 1)]);
-#endif
                 };
 
                 // prologue: k-slab 0 of the first layer (no MFMAs to hide under yet), first W2' group, first rows
@@ -583,6 +588,38 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     chunk_a(ge); chunk_b(); chunk_c(ge);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                loop_event(pf, w, lane, 51);
+                if constexpr (TWO) {
+                    // two-term stages: 8 MFMAs per k-slab (W_lo' x a, W_hi' x a for the four output tiles), the 12 chunks of
+                    // k-slab s+1 spread over them (1, 2, 1, 2, ...)
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int oh = i / 4, m4 = i % 4;
+                            if (m4 == 0) {
+                                const int ng = 2 * s + oh + 1;
+                                if (ng < 16) load_a(ng >> 1, ng & 1);
+                            }
+                            {
+                                const uint4& a = af[oh][(m4 < 2 ? 2 : 0) + (m4 & 1)];          // lo, lo, hi, hi
+                                c2[2 * oh + (m4 & 1)] = mfma_h(a, fh[s & 1], c2[2 * oh + (m4 & 1)]);
+                            }
+                            if (i < 4 && s < 6 && !(s & 1)) load_qc((s + 2) >> 1, i);
+                            if (i == 7 && s < 6 && !(s & 1)) g1 = mfma_h(gaf[(s + 2) >> 1], xf, Qc);
+                            if (s < 7) {
+#pragma unroll
+                                for (int k = (3 * i) / 2; k < (3 * (i + 1)) / 2; ++k) {
+                                    const int ge = 4 * (s + 1) + k / 3, ph = k % 3;
+                                    if (ph == 0) { if ((ge & 1) == 0 && (ge >> 1) + 1 < 16) load_pq((ge >> 1) + 1); chunk_a(ge); }
+                                    if (ph == 1) chunk_b();
+                                    if (ph == 2) chunk_c(ge);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                } else
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     // stage s: the 12 MFMAs of k-slab s, k-slab s+1 of the first layer in their shadow (one chunk per MFMA)
@@ -607,6 +644,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                loop_event(pf, w, lane, 52);
                 const float m = ok ? float(m_raw) : 0.0f;
                 TileVecs tv[2];                                 // two named buffers: no register copies between tiles
                 tv[0] = load_vecs(0);
@@ -618,6 +656,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     epilogue(c2[mt], mt, tv[mt & 1], m);
                 }
                 if (ATT) attend(c2, m);
+                loop_event(pf, w, lane, 53);
             }
             if (EQUIV) {
                 // s = w7'.u2 over all 128 features: this lane summed its half's 64, the other half holds the rest
@@ -633,6 +672,8 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             }
         }
     }
+    __builtin_amdgcn_s_setprio(0);
+    prof_event(pf, w, lane, EQUIV ? 121 : 120);       // (diagnostics builds) this wave left the loop; the barrier follows
     lds_barrier();                         // every wave left the loop: P (v.A), Q (v.B), v.W are dead -> partial sums
     if (slot_ok) {
         if (!EQUIV) {
@@ -982,7 +1023,7 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nown, int w, int lan
     const float bias = half ? 0.0f : vecs[32 * nt + c];                    // b1' (b5')
     const float bias3 = GCLP ? vecs[4 * HID + 32 * nt + c] : 0.0f;         // b3'
     float inv = 1.0f, inv3 = 1.0f;
-    if (PREC == 1) {
+    if (PREC != 0) {
         float S1 = 1.0f;                                                   // sender rows: times S1 (see geo_scale)
         if (half && !TEAM) {
             const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
@@ -1067,7 +1108,7 @@ __device__ __forceinline__ void team_exchange_q(const Lds& v, int nb, int tid, c
         if (first) v.fmax[FM_X02] = x2b;
     }
     float S1 = 1.0f;
-    if (PREC == 1) {
+    if (PREC != 0) {
         const float x2 = __uint_as_float(x2b), x02 = first ? x2 : __uint_as_float(v.fmax[FM_X02]);
         S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(sc, 6)), scale_for(4.0f * x02) * scale_for(cload(sc, 7)));
     }
@@ -1094,7 +1135,7 @@ __device__ __forceinline__ void open_pass(const Lds& v, int nb, int nown, const 
     if (nx.base == nullptr) return;
     const LaneIds q = lane_ids();
     const int w = q.w, lane = q.lane;
-    const float s_hf = (PREC == 1) ? __uint_as_float(v.fmax[FS_HS]) : 1.0f;
+    const float s_hf = (PREC != 0) ? __uint_as_float(v.fmax[FS_HS]) : 1.0f;
     const float* sc = nx.base + (nx.equiv ? E_SCALE : G_SCALE);
     if (nx.equiv) pre_phase<PREC, false, TEAM>(v, nown, w, lane, pw, nx.base + E_VEC, sc, nullptr, s_hf);
     else pre_phase<PREC, true, TEAM>(v, nown, w, lane, pw, nx.base + G_VEC, sc, hs, s_hf);
@@ -1120,9 +1161,9 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 12);
-    if (PREC == 1 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
+    if (PREC != 0 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
     float sa = 1.0f, accs = 1.0f;
-    if (PREC == 1) {
+    if (PREC != 0) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);     // senders: any atom of the molecule
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);            // >= |P_i| + |Q_j|
@@ -1161,12 +1202,12 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     prof_event(pf, w, lane, 20);
     AggRegs ar;
     const float am = pair_reduce_gcl(v, nown, nb, tid, ar, mean ? 1.0f / float(N) : 1.0f);
-    if (PREC == 1) block_max(&v.fmax[FM_AGG], am, lane);
+    if (PREC != 0) block_max(&v.fmax[FM_AGG], am, lane);
     prof_event(pf, w, lane, 21);
     lds_barrier();                         // every partial read: P, Q, H, W2' regions are free; max |agg| known
     prof_event(pf, w, lane, 22);
     float hmax = 0.0f, aggmax = 0.0f, s_agg = 1.0f;
-    if (PREC == 1) {
+    if (PREC != 0) {
         hmax = __uint_as_float(v.fmax[FM_H0 + par]);
         aggmax = __uint_as_float(v.fmax[FM_AGG]);
         s_agg = scale_for(aggmax);
@@ -1178,9 +1219,9 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     }
     // bounds: |y3| <= L1(W3a') max|h| + L1(W3b') max|agg| + max|b3'|  >= |t| ;  |h_new| <= max|h| + L1(W4') |t| + max|b4|
     const float y3b = cload(sc, SC_L1_W3A) * hmax + cload(sc, SC_L1_W3B) * aggmax + cload(sc, SC_B3);
-    const float s_t = (PREC == 1) ? scale_for(y3b) : 1.0f;
-    const float s_hn = (PREC == 1) ? scale_for(hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4)) : 1.0f;
-    const float inv1 = (PREC == 1) ? inv_pow2(s_agg * cload(sc, 3)) : 1.0f, inv2 = (PREC == 1) ? inv_pow2(s_t * cload(sc, 4)) : 1.0f;
+    const float s_t = (PREC != 0) ? scale_for(y3b) : 1.0f;
+    const float s_hn = (PREC != 0) ? scale_for(hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4)) : 1.0f;
+    const float inv1 = (PREC != 0) ? inv_pow2(s_agg * cload(sc, 3)) : 1.0f, inv2 = (PREC != 0) ? inv_pow2(s_t * cload(sc, 4)) : 1.0f;
     prof_event(pf, w, lane, 23);
     lds_barrier();
     prof_event(pf, w, lane, 14);
@@ -1249,10 +1290,10 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) hs[HS_HO + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hnew[reg];
         }
-        if (PREC == 1) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
+        if (PREC != 0) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
     }
     if (tid == 0) {
-        if (PREC == 1) v.fmax[FS_HS] = __float_as_uint(s_hn);
+        if (PREC != 0) v.fmax[FS_HS] = __float_as_uint(s_hn);
         v.misc[CX_PAR] = par ^ 1;
     }
     prof_event(pf, w, lane, 16);
@@ -1282,7 +1323,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     const int w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
-    if (PREC == 1) {
+    if (PREC != 0) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
@@ -1309,7 +1350,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
     const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
     pair_reduce_equiv(v, nown, nb, tid, xscale);
-    if (TEAM && PREC == 1 && tid == 0) v.fmax[FM_XOWN] = 0u;
+    if (TEAM && PREC != 0 && tid == 0) v.fmax[FM_XOWN] = 0u;
     lds_barrier();                         // partials read: P, Q, W2' regions are free
     stage_next(v, nx, w, tid);
     if constexpr (TEAM) {
@@ -1317,7 +1358,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
             for (int e = tid; e < nown * 32; e += THREADS)
                 *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = *reinterpret_cast<const float4*>(hs + HS_HF + (e >> 5) * HID + 4 * (e & 31));
     } else {
-        if (PREC == 1 && tid == 0) v.fmax[FM_X2] = 0u;
+        if (PREC != 0 && tid == 0) v.fmax[FM_X2] = 0u;
         lds_barrier();
     }
     float n2 = 0.0f;
@@ -1335,7 +1376,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
             n2 = fmaf(xn, xn, n2);
         }
     }
-    if (PREC == 1) block_max(&v.fmax[TEAM ? FM_XOWN : FM_X2], n2, lane);       // (a team: the own atoms; the exchange headers carry it)
+    if (PREC != 0) block_max(&v.fmax[TEAM ? FM_XOWN : FM_X2], n2, lane);       // (a team: the own atoms; the exchange headers carry it)
     prof_event(pf, w, lane, 34);
     lds_barrier();
     prof_event(pf, w, lane, 10);
@@ -1363,7 +1404,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int lane = tid & 63;
     if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
     prof_event(pf, w, lane, 1);
-    if (PREC == 1) {
+    if (PREC != 0) {
         if (tid < 8) v.fmax[tid] = 0u;
         __syncthreads();
     }
@@ -1377,7 +1418,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         v.xs[4 * a + k] = xv;
         v.x0[4 * a + k] = xv;
     }
-    if (PREC == 1) {                           // max |x|^2 at entry (a team: of the own atoms, for its first exchange header)
+    if (PREC != 0) {                           // max |x|^2 at entry (a team: of the own atoms, for its first exchange header)
         float n2 = 0.0f;
         if (tid < nown) {
             const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
@@ -1421,14 +1462,14 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
             }
             hmax = fmaxf(hmax, fabsf(acc));
         }
-        if (PREC == 1) block_max(&v.fmax[FM_H0], hmax, lane);
+        if (PREC != 0) block_max(&v.fmax[FM_H0], hmax, lane);
     }
     __syncthreads();
     {   // fragment rows of the embedded h -> v.C
-        const float s0 = (PREC == 1) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
+        const float s0 = (PREC != 0) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
         for (int e = tid; e < nown * 32; e += THREADS)
             put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), *reinterpret_cast<const float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)), s0);
-        if (PREC == 1 && tid == 0) v.fmax[FS_HS] = __float_as_uint(s0);
+        if (PREC != 0 && tid == 0) v.fmax[FS_HS] = __float_as_uint(s0);
     }
     __syncthreads();
     prof_event(pf, w, lane, 2);
@@ -2048,7 +2089,7 @@ static int32_t check_cfg(const dl_config* c) {
     if (c->in_node_nf + 1 + c->context_node_nf > FINP) return DL_ERR_UNSUPPORTED;
     if (c->n_layers < 1 || c->n_layers > 64) return DL_ERR_UNSUPPORTED;
     if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
-    if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_F16X3) return DL_ERR_UNSUPPORTED;
+    if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_F16X3 && c->precision != DL_PRECISION_F16X2) return DL_ERR_UNSUPPORTED;
     if ((c->attention | 1) != 1 || (c->tanh | 1) != 1 || (c->aggregation_mean | 1) != 1) return DL_ERR_BAD_ARG;
     if ((c->sin_embedding | 1) != 1) return DL_ERR_BAD_ARG;
     if (c->tanh && !(c->coords_range > 0.0f)) return DL_ERR_BAD_ARG;
@@ -2070,7 +2111,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     const size_t total = size_t(OFF_BLOCKS) + size_t(L) * BLOCK_SIZE;
     float* hp = static_cast<float*>(calloc(total, sizeof(float)));
     if (!hp) return DL_ERR_ALLOC;
-    const bool f16 = cfg->precision == DL_PRECISION_F16X3;
+    const bool f16 = cfg->precision != DL_PRECISION_FP32;
     auto unit = [&](float* d, const float* ww, int ld, int col0, double sc) -> float {
         if (f16) return float(pack_unit_f16(d, ww, ld, col0, sc));
         pack_unit(d, ww, ld, col0, sc);
@@ -2275,11 +2316,14 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
     const int32_t rc = fc_workspace(B, team, workspace, workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
     a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
-    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3, att = m->cfg.attention != 0;
+    // (the two-term GCL loop of F16X2 has no attention variant: an attention model runs its F16X3 kernels)
+    const bool f16 = m->cfg.precision != DL_PRECISION_FP32, att = m->cfg.attention != 0, two = m->cfg.precision == DL_PRECISION_F16X2 && !att;
     const void* kernel;
-    if (team <= 1) kernel = f16 ? (att ? (const void*)&egnn_forward_fc_kernel<1, false, true> : (const void*)&egnn_forward_fc_kernel<1, false, false>)
+    if (team <= 1) kernel = two ? (const void*)&egnn_forward_fc_kernel<2, false, false>
+                          : f16 ? (att ? (const void*)&egnn_forward_fc_kernel<1, false, true> : (const void*)&egnn_forward_fc_kernel<1, false, false>)
                                 : (att ? (const void*)&egnn_forward_fc_kernel<0, false, true> : (const void*)&egnn_forward_fc_kernel<0, false, false>);
-    else kernel = f16 ? (att ? (const void*)&egnn_forward_fc_kernel<1, true, true> : (const void*)&egnn_forward_fc_kernel<1, true, false>)
+    else kernel = two ? (const void*)&egnn_forward_fc_kernel<2, true, false>
+                : f16 ? (att ? (const void*)&egnn_forward_fc_kernel<1, true, true> : (const void*)&egnn_forward_fc_kernel<1, true, false>)
                       : (att ? (const void*)&egnn_forward_fc_kernel<0, true, true> : (const void*)&egnn_forward_fc_kernel<0, true, false>);
     if (team <= 1) {
         void* params[] = {&a};
@@ -2314,11 +2358,13 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     const int32_t rc = fc_workspace(g->B, g->team, g->workspace, g->workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
     a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
-    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3, att = m->cfg.attention != 0;
+    const bool f16 = m->cfg.precision != DL_PRECISION_FP32, att = m->cfg.attention != 0, two = m->cfg.precision == DL_PRECISION_F16X2 && !att;
     const void* kernel;
-    if (g->team <= 1) kernel = f16 ? (att ? (const void*)&sample_chain_fc_kernel<1, false, true> : (const void*)&sample_chain_fc_kernel<1, false, false>)
+    if (g->team <= 1) kernel = two ? (const void*)&sample_chain_fc_kernel<2, false, false>
+                             : f16 ? (att ? (const void*)&sample_chain_fc_kernel<1, false, true> : (const void*)&sample_chain_fc_kernel<1, false, false>)
                                    : (att ? (const void*)&sample_chain_fc_kernel<0, false, true> : (const void*)&sample_chain_fc_kernel<0, false, false>);
-    else kernel = f16 ? (att ? (const void*)&sample_chain_fc_kernel<1, true, true> : (const void*)&sample_chain_fc_kernel<1, true, false>)
+    else kernel = two ? (const void*)&sample_chain_fc_kernel<2, true, false>
+                : f16 ? (att ? (const void*)&sample_chain_fc_kernel<1, true, true> : (const void*)&sample_chain_fc_kernel<1, true, false>)
                       : (att ? (const void*)&sample_chain_fc_kernel<0, true, true> : (const void*)&sample_chain_fc_kernel<0, true, false>);
     if (g->team <= 1) {
         a.a.team = 1;

@@ -529,7 +529,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             r = dx * dx + dy * dy + dz * dz;
             d0 = ex * ex + ey * ey + ez * ez;
         }
-        if (PREC == 1) pqb = w.pmax[i] + w.qmax[j0];
+        if (PREC != 0) pqb = w.pmax[i] + w.qmax[j0];
     }
     // rows of the CURRENT tile (requested one tile ahead): the P rows of the quads' receiving atoms and the 32 senders' Q rows
     float2 p2[4] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
@@ -573,7 +573,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             const float4 dd = *reinterpret_cast<const float4*>(w.X0 + 4 * jn0);
             xn[0] = a.x; xn[1] = a.y; xn[2] = a.z; xn[3] = b.x; xn[4] = b.y; xn[5] = b.z;
             xn[6] = cc.x; xn[7] = cc.y; xn[8] = cc.z; xn[9] = dd.x; xn[10] = dd.y; xn[11] = dd.z;
-            if (PREC == 1) pq_n = w.pmax[i_n] + w.qmax[jn0];
+            if (PREC != 0) pq_n = w.pmax[i_n] + w.qmax[jn0];
             request_rows(i_n, jn0, p2n, qn);
         };
         float emb[SIN ? SIN_K : 1];
@@ -659,15 +659,20 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                     us[4 * q + 2] = silu_scaled(y.z, isa); us[4 * q + 3] = silu_scaled(y.w, isa);
                 }
                 uint4 ah, al;
-                split8(us, ah, al);
+                // PREC 2 (F16X2, GCL without attention): the activation enters as one fp16 rounded to nearest, no lo part
+                constexpr bool TWO = (PREC == 2) && !EQUIV && !ATT;
+                if constexpr (TWO) ah = round8(us);
+                else split8(us, ah, al);
                 uint4 bh[4], bl[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
                     bh[nt] = Wq[(slab * 4 + nt) * 64];
                     bl[nt] = Wq[((8 + slab) * 4 + nt) * 64];
                 }
-                acc0 = mfma_h(al, bh[0], acc0); acc1 = mfma_h(al, bh[1], acc1);
-                acc2 = mfma_h(al, bh[2], acc2); acc3 = mfma_h(al, bh[3], acc3);
+                if constexpr (!TWO) {
+                    acc0 = mfma_h(al, bh[0], acc0); acc1 = mfma_h(al, bh[1], acc1);
+                    acc2 = mfma_h(al, bh[2], acc2); acc3 = mfma_h(al, bh[3], acc3);
+                }
                 acc0 = mfma_h(ah, bl[0], acc0); acc1 = mfma_h(ah, bl[1], acc1);
                 acc2 = mfma_h(ah, bl[2], acc2); acc3 = mfma_h(ah, bl[3], acc3);
                 acc0 = mfma_h(ah, bh[0], acc0); acc1 = mfma_h(ah, bh[1], acc1);
@@ -881,7 +886,7 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
 
     const int row_tiles = (V + 31) / 32;
     const int edge_grid = 512;                                     // 2 workgroups per CU (64 KB LDS each)
-    const bool f16 = m->cfg.precision == DL_PRECISION_F16X3;
+    const bool f16 = m->cfg.precision != DL_PRECISION_FP32, two = m->cfg.precision == DL_PRECISION_F16X2;
     auto node = [&](const float* post, const float* pre_units, const float* pre_bias, const float* pre_scale) {
         if (f16) hipLaunchKernelGGL(pk_node_kernel<1>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
         else hipLaunchKernelGGL(pk_node_kernel<0>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
@@ -901,7 +906,9 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
                 else if (weighted) DL_EDGE(false, 0, true, true);
                 else DL_EDGE(false, 0, false, true);
             } else {
-                if (f16 && weighted) DL_EDGE(false, 1, true, false);
+                if (two && weighted) DL_EDGE(false, 2, true, false);
+                else if (two) DL_EDGE(false, 2, false, false);
+                else if (f16 && weighted) DL_EDGE(false, 1, true, false);
                 else if (f16) DL_EDGE(false, 1, false, false);
                 else if (weighted) DL_EDGE(false, 0, true, false);
                 else DL_EDGE(false, 0, false, false);

@@ -145,6 +145,19 @@ __device__ __forceinline__ void split8(const float (&u)[8], uint4& hi, uint4& lo
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// 8 scaled fp32 values -> one fragment of fp16 rounded to nearest (v_cvt_pk_f16_f32): the two-term scheme of DL_PRECISION_F16X2
+__device__ __forceinline__ uint4 round8(const float (&u)[8]) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    unsigned h[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float2v p = {u[2 * q], u[2 * q + 1]};
+        h[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(p, half2v));
+    }
+    return make_uint4(h[0], h[1], h[2], h[3]);
+}
+
 __device__ __forceinline__ floatx16 mfma_h(const uint4& a, const uint4& b, floatx16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
 }

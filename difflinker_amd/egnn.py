@@ -209,7 +209,10 @@ class Dynamics(nn.Module):
         self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
         self._hip_models = {}                          # device index -> (_HipModel, weight version)
         # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'f16x3' = scaled split-fp16 on the
-        # matrix cores (default, ~3e-6 rel-L2 on a 500-step chain), 'fp32' = exact fp32 MFMA.
+        # matrix cores (default, fp32-class: 2..5e-7 rel-L2 on the node features of a forward), 'fp32' = exact fp32 MFMA,
+        # 'f16x2' (opt-in, round 4) = f16x3 except the second layer of the GCL edge model, whose input enters as one fp16 rounded
+        # to nearest (two MFMA terms instead of three: +9..11 % molecules/s; node features 3..9e-6 rel-L2 per forward, velocities
+        # and sampled coordinates as f16x3 - inside the 1e-4 bar, not fp32-class; include/difflinker_hip.h).
         self.precision = os.environ.get('DIFFLINKER_PRECISION', 'f16x3')
         # compute units per molecule on the LDS-resident path (not a reference hyper-parameter): 'auto' = as many (1, 2,
         # 4 or 8) as keep the whole chip busy for the batch at hand - the reference's default sampling batch of 64
@@ -515,7 +518,7 @@ class DynamicsWithPockets(Dynamics):
     ``edge_mask`` is the per-node batch-index vector ``[B*N]`` of the pockets' ``collate`` (datasets.py:359-364);
     the last two context channels are the fragment-only / pocket-only masks.  The graph (ligand-ligand fully
     connected, pocket-pocket <= 4 A, ligand-pocket <= 10 A or 4 A) is rebuilt on the GPU every call and the EGNN
-    runs without an edge mask.  Same arithmetic modes as ``Dynamics`` (``precision`` = 'f16x3' | 'fp32')."""
+    runs without an edge mask.  Same arithmetic modes as ``Dynamics`` (``precision`` = 'f16x3' | 'fp32' | 'f16x2')."""
 
     GRAPH_TYPES = {'4A': 0, 'FC-4A': 1, 'FC-10A-4A': 2}
 

@@ -27,6 +27,8 @@ CONFIGS = {
     # not a BASELINE configuration: GEOM hparams on molecules of 60..80 atoms - beyond one compute unit's LDS (55 atoms):
     # round 3 runs them fused on teams of two compute units, round 2 on the HBM-resident kernels under a host-driven loop
     'C2L': dict(nf=9, ctx=1, n_layers=6, batch=64, n_max=80, n_lo=60, linker=(3, 12), T=500, graph_type='FC'),
+    # beyond the fused paths (> 110 atoms per molecule): HBM-resident per-pass kernels under a host-driven T-step loop
+    'C2XL': dict(nf=9, ctx=1, n_layers=6, batch=32, n_max=150, n_lo=120, linker=(3, 12), T=500, graph_type='FC'),
 }
 
 
@@ -181,6 +183,18 @@ def flops_executed(hidden_nf, n_layers, fin, pairs, pairs_coord, nodes):
     coord_pair = 2 * ((hn * hn + 2 * hn) + hn)
     per_node = 2 * (2 * (2 * hn * hn + hn * hn)) + 2 * 3 * (2 * hn * hn)
     return n_layers * (pairs * gcl_pair + pairs_coord * coord_pair + nodes * per_node) + nodes * 4 * fin * hn
+
+
+def split_terms(precision, hidden_nf, n_layers, fin, pairs, pairs_coord, nodes):
+    """fp16 MFMA terms per multiply-accumulate, averaged over the executed work: 3 in 'f16x3' (hi*hi' + hi*lo' + lo*hi'), and in
+    'f16x2' 2 for the GCL edge models' second layer (the activation enters as one fp16) and 3 for everything else.  The
+    algorithmic-flop ceiling of a split scheme is the dense f16 MFMA peak divided by this figure."""
+    if precision != 'f16x2':
+        return 3.0
+    hn = hidden_nf
+    total = flops_executed(hidden_nf, n_layers, fin, pairs, pairs_coord, nodes)
+    gcl = n_layers * pairs * 2 * (2 * (hn * hn + 2 * hn))
+    return (2.0 * gcl + 3.0 * (total - gcl)) / total
 
 
 def coord_pair_count(data):

@@ -73,8 +73,13 @@ typedef enum dl_status {
  *   DL_PRECISION_F16X3  each fp32 operand is scaled by a power of two into the fp16 range and split into
  *                       fp16 hi+lo (~21 significant bits); a*w = hi*hi'+hi*lo'+lo*hi' on
  *                       v_mfma_f32_32x32x16_f16 with fp32 accumulation, rescaled exactly; ~1e-6 relative
- *                       per product (fp32-class), 2x faster than the fp32 MFMA on this workload      */
-typedef enum dl_precision { DL_PRECISION_FP32 = 0, DL_PRECISION_F16X3 = 1 } dl_precision;
+ *                       per product (fp32-class), 2x faster than the fp32 MFMA on this workload
+ *   DL_PRECISION_F16X2  (round 4, opt-in) F16X3 everywhere except the second layer of the GCL edge model (src/egnn.py:19-30,45-59),
+ *                       where the first layer's activation enters as ONE fp16 rounded to nearest: a_rn*(hi'+lo'), 64 instead of
+ *                       96 MFMAs per 32 pairs and no lo split (+9..11 % molecules/s).  Measured against the fp32 oracle: node
+ *                       features 3e-6..9e-6 rel-L2 per forward (F16X3: 2e-7..5e-7), velocities and sampled coordinates
+ *                       unchanged (<= 1e-6; the coordinate model stays F16X3) - inside the 1e-4 bar, outside fp32 class       */
+typedef enum dl_precision { DL_PRECISION_FP32 = 0, DL_PRECISION_F16X3 = 1, DL_PRECISION_F16X2 = 2 } dl_precision;
 
 /* Dynamics.__init__ hyper-parameters (src/egnn.py:324-329).  The HIP path implements the
  * released-config surface (model='egnn_dynamics', SiLU, hidden_nf=128, inv_sublayers=2) plus the optional attention, tanh,

@@ -65,7 +65,8 @@ dyn.forward(**args)
 torch.cuda.synchronize()
 lib.dl_set_profile_buffer(None)
 ev = buf.cpu()
-names = {(1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: barrier', (12, 13): 'gcl: PAIR loop + partials',
+names = {(12, 120): 'gcl: PAIR loop, this wave', (120, 13): 'gcl: wait for the other waves + partials', (32, 121): 'eq: PAIR loop, this wave',
+         (121, 33): 'eq: wait for the other waves + partials', (1, 2): 'embedding', (10, 11): 'gcl: stage+proj P,Q', (11, 12): 'gcl: barrier', (12, 13): 'gcl: PAIR loop + partials',
          (13, 14): 'gcl: reduce + h->lds', (13, 20): 'gcl: barrier (partials complete)', (20, 21): 'gcl: sum of slot partials',
          (21, 22): 'gcl: barrier (partials read)', (22, 23): 'gcl: h rows + W2\' DMA issue, agg store, max', (23, 25): 'gcl: wait for the h rows (LDS-DMA)', (25, 14): 'gcl: barrier (h, agg in place)', (20, 23): 'gcl: team exchange', (14, 15): 'gcl: node mlp 1', (15, 16): 'gcl: barrier+node mlp 2',
          (16, 10): 'gcl: end barrier', (16, 30): 'gcl: end barrier', (30, 31): 'eq: stage+proj', (31, 32): 'eq: barrier',
@@ -98,7 +99,24 @@ for w in range(8):
         if key in inloop:
             loop[kind][inloop[key]] = loop[kind].get(inloop[key], 0) + ts[k + 1] - ts[k]
             if key == (40, 41): cnt[kind] += 1
-    segs = [(tg, t_) for tg, t_ in zip(tags, ts) if 40 <= tg < 100]
+    # -DDL_PROFILE_LOOP builds: 50 = a step begins, 51 = k-slab 0 produced, 52 = the matrix section is over, 53 = the epilogue is over
+    step = {'gcl': collections.OrderedDict(), 'eq': collections.OrderedDict()}
+    nstep = {'gcl': 0, 'eq': 0}
+    kind = 'gcl'
+    stepnames = {(50, 51): 'open + k-slab 0', (51, 52): 'matrix section (MFMAs + first layer)', (52, 53): 'epilogue', (53, 50): 'between steps'}
+    for k in range(n - 1):
+        if tags[k] == 12: kind = 'gcl'
+        if tags[k] == 32: kind = 'eq'
+        key = (tags[k], tags[k + 1])
+        if key in stepnames:
+            step[kind][stepnames[key]] = step[kind].get(stepnames[key], 0) + ts[k + 1] - ts[k]
+            if key == (50, 51): nstep[kind] += 1
+    if w in (0, 3, 4, 7):
+        for kind_ in ('gcl', 'eq'):
+            if nstep[kind_]:
+                print(f'   wave {w}: {nstep[kind_]} {kind_} steps, ticks per step: ' +
+                      ', '.join(f'{nm} {v // nstep[kind_]}' for nm, v in step[kind_].items()) + f' | sum {sum(step[kind_].values()) // nstep[kind_]}')
+    segs = [(tg, t_) for tg, t_ in zip(tags, ts) if 40 <= tg < 50]
     if segs and w in (0, 4):
         # ping-pong builds: (40+k) = segment k of steps 2..3 finished, (60+k) = barrier k released; first pass only
         first = []
