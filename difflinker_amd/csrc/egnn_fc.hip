@@ -29,6 +29,7 @@
 #include <cmath>
 
 #include <algorithm>
+#include <atomic>
 
 #include "../../include/difflinker_hip.h"
 #include "pack_layout.h"
@@ -1898,8 +1899,15 @@ __global__ void sampler_step_kernel(int total, int D, const float* __restrict__ 
 // Host side: weight packing and the C ABI
 // ---------------------------------------------------------------------------------------------------
 thread_local int g_last_hip = 0;
-int g_team_fault = 0;                       // tests only (dl_debug_team_fault): member 1 of every team gives up at its first exchange
+std::atomic<int> g_team_fault{0};          // tests only (dl_debug_team_fault): that many of the NEXT team launches fail (member 1 gives up at once)
 unsigned long long* g_prof_buf = nullptr;   // diagnostics only (dl_set_profile_buffer)
+
+// one injected failure per team launch while the counter is positive (it cannot stay on by accident: ADVICE round 3)
+inline int take_team_fault() {
+    int n = g_team_fault.load();
+    while (n > 0 && !g_team_fault.compare_exchange_weak(n, n - 1)) {}
+    return n > 0 ? 1 : 0;
+}
 
 inline bool hip_ok(hipError_t e) {
     if (e != hipSuccess) { g_last_hip = int(e); return false; }
@@ -2066,7 +2074,7 @@ int32_t dl_profile_max_events(void) { return 0; }      // the phase timeline exi
 void dl_set_profile_buffer(void* device_buf) { g_prof_buf = static_cast<unsigned long long*>(device_buf); }
 int32_t dl_last_hip_error(void) { return g_last_hip; }
 int32_t dl_max_atoms(void) { return NMAX; }
-void dl_debug_team_fault(int32_t on) { g_team_fault = on; }
+void dl_debug_team_fault(int32_t launches) { g_team_fault.store(launches < 0 ? 0 : launches); }
 
 const char* dl_error_string(int32_t s) {
     switch (s) {
@@ -2315,7 +2323,7 @@ int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const f
     FcWorkspace ws;
     const int32_t rc = fc_workspace(B, team, workspace, workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
-    a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
+    a.team = team <= 1 ? 1 : team; a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = team > 1 ? take_team_fault() : 0;
     // (the two-term GCL loop of F16X2 has no attention variant: an attention model runs its F16X3 kernels)
     const bool f16 = m->cfg.precision != DL_PRECISION_FP32, att = m->cfg.attention != 0, two = m->cfg.precision == DL_PRECISION_F16X2 && !att;
     const void* kernel;
@@ -2357,7 +2365,7 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     FcWorkspace ws;
     const int32_t rc = fc_workspace(g->B, g->team, g->workspace, g->workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
-    a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g_team_fault;
+    a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g->team > 1 ? take_team_fault() : 0;
     const bool f16 = m->cfg.precision != DL_PRECISION_FP32, att = m->cfg.attention != 0, two = m->cfg.precision == DL_PRECISION_F16X2 && !att;
     const void* kernel;
     if (g->team <= 1) kernel = two ? (const void*)&sample_chain_fc_kernel<2, false, false>

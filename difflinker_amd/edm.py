@@ -19,6 +19,7 @@ Out of scope (training only): ``EDM.forward`` and the likelihood/KL terms (edm.p
 ``GammaNetwork`` schedule.
 """
 import ctypes
+import warnings
 
 import numpy as np
 import torch
@@ -253,8 +254,22 @@ class EDM(torch.nn.Module):
             if noise_bank is None and self.noise_source == 'philox':
                 philox_draws = (int(self.noise_seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset))   # one draw per step, no bank
                 self.noise_seed = int(self.noise_seed) + 1
-            return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
-                                                keep_frames, noise_bank, philox_draws)
+            # a centering / sin_embedding Dynamics may still pick a team for its forward calls (small batch, 56..110 atoms): should
+            # one fail to assemble, the chain is sampled again without teams - from the SAME draws (generator state restored) - and
+            # nothing but FoundNaNException reaches the caller
+            if not hasattr(self.dynamics, 'without_teams'):
+                return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
+                                                    keep_frames, noise_bank, philox_draws)
+            rng = None
+            if noise_bank is None and philox_draws is None and x.device.type == 'cuda':
+                rng = torch.cuda.get_rng_state(x.device)
+
+            def host_loop():
+                if rng is not None:
+                    torch.cuda.set_rng_state(rng, x.device)
+                return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
+                                                    keep_frames, noise_bank, philox_draws)
+            return self.dynamics.without_teams(host_loop)
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.EDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
@@ -302,16 +317,40 @@ class EDM(torch.nn.Module):
             if small is not None:
                 fused.append((small, None))
             if med is not None:
-                fused += [(c, max(2, dyn.team_for_size(int(c.numel()), dev))) for c in dyn.team_chunks(med, dev)]
+                # team size of the 56..110-atom molecules: that of the WHOLE (possibly sharded) batch when the caller pinned it
+                # (EDM.team_batch, distributed.sample_chain_sharded) - an atom's messages are summed in a team-size dependent
+                # order, so a sample must not depend on how the batch was split - else of the piece at hand
+                def med_team(count):
+                    ref = count if self.team_batch is None else max(count, int(self.team_batch))
+                    return max(2, dyn.team_for_size(int(ref), dev))
+                fused += [(c, med_team(int(c.numel()))) for c in dyn.team_chunks(med, dev)]
+            # every part reports NaNs in ITS numbering; the reference's callers index the batch with the sets of the exception
+            # (lightning.py:353-361): collect them in whole-batch numbering and raise once, for the earliest denoiser call
+            nan_sets = []
+
+            def run_part(idx, fn):
+                try:
+                    return fn()
+                except utils.FoundNaNException as e:
+                    rows = idx.tolist()
+                    nan_sets.append(tuple({rows[k] for k in s_} for s_ in (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx)))
+                    return None
             for idx, team in fused:
                 bank = None if philox else (noise_bank[0][:, idx].contiguous(), noise_bank[1][:, idx].contiguous())
-                chain[:, idx] = self._sample_chain_fused(keep_frames=keep_frames, noise_bank=bank, seed=seed, mol_offset=mol_offset,
-                                                         mol_index=idx.to(torch.int32).contiguous(), team=team, **part(idx))
+                got = run_part(idx, lambda: self._sample_chain_fused(keep_frames=keep_frames, noise_bank=bank, seed=seed,
+                                                                     mol_offset=mol_offset, mol_index=idx.to(torch.int32).contiguous(),
+                                                                     team=team, **part(idx)))
+                if got is not None:
+                    chain[:, idx] = got
             if big is not None:
                 bank = None if philox else (noise_bank[0][:, big], noise_bank[1][:, big])
-                large = self._sample_chain_host_loop(keep_frames=keep_frames, noise_bank=bank,
-                                                     philox_draws=(seed, int(mol_offset), big, bs) if philox else None, **part(big))
-                chain[:, big] = large.to(chain.dtype)
+                large = run_part(big, lambda: self._sample_chain_host_loop(
+                    keep_frames=keep_frames, noise_bank=bank, philox_draws=(seed, int(mol_offset), big, bs) if philox else None,
+                    **part(big)))
+                if large is not None:
+                    chain[:, big] = large.to(chain.dtype)
+            if nan_sets:
+                raise utils.FoundNaNException.from_index_sets(*(set().union(*(s_[k] for s_ in nan_sets)) for k in range(3)))
         finally:
             self.coef_batch = pinned
         return chain
@@ -345,6 +384,16 @@ class EDM(torch.nn.Module):
         if team is None:
             team = 1 if self.dynamics._no_teams else \
                 self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)), dev)
+        if team == 1 and not getattr(EDM, '_warned_off_sweet_spot', False):
+            # one compute unit per molecule for the whole chain: a batch just above the number of compute units waits for a few
+            # straggler molecules on an otherwise idle chip (measured: B = 257 costs 1.3x B = 256 on 256 compute units) - say so once
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            if cus < bs < 2 * cus:
+                EDM._warned_off_sweet_spot = True
+                warnings.warn(f'EDM.sample_chain: a batch of {bs} molecules on {cus} compute units runs one molecule per compute unit '
+                              f'for the whole chain, so the {bs - cus} molecules beyond {cus} start only when others have finished '
+                              f'(B = 257 takes 1.3x the time of B = 256); batches of k x {cus} molecules (or <= {cus}) use the chip '
+                              f'evenly', RuntimeWarning, stacklevel=3)
         ws, ws_bytes = self.dynamics.workspace(bs, team, dev)
         args = _lib.DLChainArgs(
             B=bs, N=n, T=T, keep_frames=keep_frames,

@@ -31,6 +31,11 @@ class FoundNaNException(Exception):
         return set(torch.nonzero(bad).flatten().tolist())
 
     @classmethod
+    def from_index_sets(cls, x_h, only_x, only_h):
+        """Build from the three index sets themselves (a batch sampled in parts: sets re-numbered to the whole batch)."""
+        return cls(x_nan_idx=set(x_h) | set(only_x), h_nan_idx=set(x_h) | set(only_h))
+
+    @classmethod
     def from_flags(cls, flags):
         """Build from the per-molecule device flag word (bit0: x NaN, bit1: h NaN)."""
         flags = flags.tolist() if hasattr(flags, 'tolist') else list(flags)

@@ -149,7 +149,8 @@ int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
 
 /* Scratch of dl_egnn_forward_fc / dl_egnn_forward_fc_team / dl_sample_chain_fc for a batch of B molecules with `team`
  * compute units per molecule (0 or 1: one): per workgroup the node features and the pre-computed half of the node MLP that
- * cross the O(n^2) edge passes through L2 (94 KB), plus, for team > 1, the exchange buffers (116 KB per molecule) and arrival words. */
+ * cross the O(n^2) edge passes through L2 (124 KB: the T0 and residual tiles in accumulator order, the h fragment rows of a
+ * 56..110-atom molecule across a coordinate pass), plus, for team > 1, the exchange buffers (116 KB per molecule) and arrival words. */
 size_t dl_workspace_bytes(int32_t B, int32_t team);
 
 /* DynamicsWithPockets.forward (src/egnn.py:470-552): radius graph rebuilt on the GPU every call
@@ -247,8 +248,9 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* s
  * dl_egnn_forward_fc_large).  With team > 1 the entry points zero nan_flags (and set nan_step to -1) on `stream` themselves. */
 int32_t dl_team_max(int32_t B);
 int32_t dl_team_max_atoms(int32_t team);
-/* tests only: when on, member 1 of every team gives up at its first exchange (exercises the fail-together path above) */
-void dl_debug_team_fault(int32_t on);
+/* tests only: member 1 of every team of the NEXT `launches` team launches gives up at its first exchange (exercises the
+ * fail-together path above); the count runs down by itself - the switch cannot stay on by accident - and 0 clears it */
+void dl_debug_team_fault(int32_t launches);
 /* dl_egnn_forward_fc with a team per molecule (team = 1: identical to dl_egnn_forward_fc) */
 int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,

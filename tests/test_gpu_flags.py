@@ -17,8 +17,11 @@ SIN_CASES = [('sin', dict(sin_embedding=True)),
 # sin_embedding: the top frequency is 2 pi 4^5 / 15 = 429 rad per Angstrom, so one fp32 ulp of a 5 A distance (4.8e-7) is 2e-4 of
 # phase: any two fp32 evaluations of the network (the reference on two devices, too) differ by that much in 4 of the 24 edge
 # features once the coordinates have gone through one block.  The arithmetic of the distances and frequencies follows the
-# reference operation by operation; what remains is measured below and bounded at 10x the plain forward tolerance.
-SIN_TOLS = {k: 10 * v for k, v in P.FWD_TOLS.items()}
+# reference operation by operation; what remains is measured (rounds 3-4: 1.2e-6 raw velocity against the reference fixture, at
+# most 5.1e-5 with tanh + a gain-1.0 head on top; chain 4e-8) and bounded at the north-star bar of 1e-4 on a forward - the plain
+# forward tolerance where no live head amplifies the phase (the former 10x / 1e-3 bars hid three orders of magnitude).
+SIN_TOLS = {k: 1e-4 for k in P.FWD_TOLS}
+SIN_TOLS_QUIET_HEAD = dict(P.FWD_TOLS)        # coordinate head at gain 0.02, no tanh: the plain forward tolerance holds
 
 
 def make(nf, ctx, L, seed, flags, precision, coord_gain):
@@ -109,7 +112,7 @@ def test_sin_embedding_forward_vs_reference_golden(golden_dir, precision):
     inp = {k: g[k] for k in ('node_mask', 'linker_mask', 'edge_mask', 'context')}
     out = P.run_hip_forward(dyn, inp, g['xh'], g['t'])
     ev, eh = P.report(f'reference flags [sin] {precision}', out, g['out_sin'], g['xh'])
-    assert ev <= SIN_TOLS[precision] and eh <= SIN_TOLS[precision]
+    assert ev <= SIN_TOLS_QUIET_HEAD[precision] and eh <= SIN_TOLS_QUIET_HEAD[precision]
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'fp32'])
@@ -122,7 +125,8 @@ def test_sin_embedding_forward_vs_oracle_geom_sized(case, precision):
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     out = P.run_hip_forward(dyn, inp, z, t)
     ev, eh = P.report(f'flags [{tag}] {precision} vs oracle', out, ref, z)
-    assert ev <= SIN_TOLS[precision] and eh <= SIN_TOLS[precision]
+    tol = SIN_TOLS if flags.get('tanh') else SIN_TOLS_QUIET_HEAD
+    assert ev <= tol[precision] and eh <= tol[precision]
     assert float(ref[..., :3].abs().max()) > 1e-4, 'the coordinate head must act in this case'
 
 
@@ -138,7 +142,7 @@ def test_sin_embedding_on_the_pocket_graph_vs_oracle():
     inp, z, t = P.pocket_inputs(batch=3, n_frag=14, n_pocket=90, linker=(5, 9), nf=nf, seed=261)
     ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     ev, eh = P.report('pocket flags [sin]', P.run_hip_forward(dyn, inp, z, t), ref, z)
-    assert ev <= SIN_TOLS['f16x3'] and eh <= SIN_TOLS['f16x3']
+    assert ev <= SIN_TOLS_QUIET_HEAD['f16x3'] and eh <= SIN_TOLS_QUIET_HEAD['f16x3']
 
 
 def test_sin_embedding_chain_vs_oracle():
@@ -162,7 +166,7 @@ def test_sin_embedding_chain_vs_oracle():
                            d['context'], keep_frames=2, noise_bank=bank.stacked()).cpu()
     err = rel_l2(got[0], want[0])
     print(f'chain with sin_embedding: final frame rel-L2 {err:.3e}')
-    assert err <= 1e-3 and torch.equal(got[0][..., 3:], want[0][..., 3:])      # atom types identical, coordinates to 1e-3
+    assert err <= 1e-4 and torch.equal(got[0][..., 3:], want[0][..., 3:])      # atom types identical, coordinates to the north-star bar (measured 4e-8)
 
 
 def test_options_on_teams_and_beyond():

@@ -131,7 +131,7 @@ def test_team_requests_the_device_cannot_hold_are_refused():
 
 
 def test_a_team_that_cannot_assemble_fails_together_and_the_call_is_rerun_without_teams():
-    """ADVICE round 2 / VERDICT item 4.  `dl_debug_team_fault` makes member 1 of every team give up at its first exchange, as a
+    """ADVICE round 2 / VERDICT item 4.  `dl_debug_team_fault(n)` makes member 1 of every team of the next n team launches give up at its first exchange, as a
     member whose team-mates never became resident would after its spin limit: it publishes the poison arrival word, every
     other member stops waiting too, ALL of them end with flag bit 3 (raw C ABI), and the Python drop-in re-runs the batch on
     one compute unit per molecule - the caller sees the oracle's numbers and no exception."""
@@ -143,7 +143,7 @@ def test_a_team_that_cannot_assemble_fails_together_and_the_call_is_rerun_withou
     inp, z, t = ragged_inputs([20, 33, 9, 50], [4, 6, 2, 9], nf, seed=17)
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     dyn.team = 4
-    lib.dl_debug_team_fault(1)
+    lib.dl_debug_team_fault(3)          # the three team launches below fail (the count runs down by itself)
     try:
         prep = dyn.prepare(inp['node_mask'].to(dev()), inp['linker_mask'].to(dev()), inp['edge_mask'].to(dev()), inp['context'].to(dev()))
         out, flags = dyn.launch(prep, t.to(dev()), z.to(dev()))
