@@ -380,15 +380,15 @@ def main():
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
         # fabric-side bytes per launch: NOT measured in this run (rocprofv3 --pmc passes cannot run inside the timed
-        # process) but taken from the committed counter passes of the same launch (profiles/r03/pmc_chain_kernel_T500.json,
+        # process) but taken from the committed counter passes of the same launch (profiles/r04/pmc_chain_kernel_T500.json,
         # collected by scripts/profile_gpu.sh on this command line; FETCH_SIZE doubled for gfx950) - labelled as such
         traffic, traffic_note = None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r03', 'pmc_chain_kernel_T500.json')
+        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04', 'pmc_chain_kernel_T500.json')
         if not pockets and precision == 'f16x3' and a.config == 'C2' and not a.uniform_size and os.path.exists(pmc_path):
             d_ = json.load(open(pmc_path))['_derived']
             per_fwd = (d_['hbm_fetch_bytes_per_launch_x2_corrected'] + d_['hbm_write_bytes_per_launch']) / float(d_['forwards_per_launch'])
             traffic = per_fwd * (cfg['T'] + 1) * (B / 256.0)
-            traffic_note = 'from_profile: FETCH_SIZE x2 + WRITE_SIZE of profiles/r03/pmc_chain_kernel_T500.json (the same launch, ' \
+            traffic_note = 'from_profile: FETCH_SIZE x2 + WRITE_SIZE of profiles/r04/pmc_chain_kernel_T500.json (the same launch, ' \
                            'separate rocprofv3 --pmc passes); fabric-side, Infinity-Cache hits included (scratch + weight ' \
                            'streaming); algorithmic HBM bytes are ~2 MB per forward'
         out = {
