@@ -499,6 +499,13 @@ class EDM(torch.nn.Module):
                 return self.dynamics.forward(xh=z_, t=t_arr_, node_mask=node_mask, linker_mask=linker_mask,
                                              context=context, edge_mask=edge_mask)
             out, flags = self.dynamics.launch(prep, t_arr_, z_)
+            if q_ == 0 and not isinstance(self.dynamics, DynamicsWithPockets) and not self.dynamics._no_teams:
+                # a Dynamics may run this loop on teams of workgroups (small batch, 56..110 atoms): should they fail to assemble
+                # (a co-tenant kernel holding compute units), say so after the FIRST launch - every further one would spin to the
+                # limit as well - and let without_teams() repeat the chain on one compute unit per molecule
+                if bool((flags & 8).any()):
+                    from .egnn import TeamNotAssembled
+                    raise TeamNotAssembled('a team of workgroups did not assemble in time (another kernel held compute units)')
             newly = (flags != 0) & (seen == 0)
             first_bad.masked_fill_(newly, q_)
             seen.bitwise_or_(flags)
