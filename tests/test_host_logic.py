@@ -371,3 +371,22 @@ def test_bench_gpus_2_starts_its_own_ranks():
     assert r.returncode != 0
     assert 'WORLD_SIZE=' not in err, err[-2000:]
     assert err.count('bench.py needs an MI355X') >= 2, err[-2000:]       # both ranks got as far as the CUDA check
+
+
+def test_found_nan_exception_from_index_sets_and_split_terms():
+    """Round-4 host helpers: the exception rebuilt from whole-batch index sets keeps the reference's three-way partition
+    (utils.py:274-289); the average number of fp16 MFMA terms per multiply-accumulate prices the f16x2 ceiling between 2 and 3."""
+    from difflinker_amd import synthetic
+    from difflinker_amd.utils import FoundNaNException
+    e = FoundNaNException.from_index_sets({3}, {0, 7}, {5})
+    assert e.x_h_nan_idx == {3} and e.only_x_nan_idx == {0, 7} and e.only_h_nan_idx == {5}
+    f = FoundNaNException.from_flags([1, 0, 2, 3])
+    assert f.only_x_nan_idx == {0} and f.only_h_nan_idx == {2} and f.x_h_nan_idx == {3}
+    data, cfg = synthetic.make_batch('C2', seed=1000, batch=16)
+    pairs, nodes = synthetic.pair_and_node_counts(data)
+    pc = synthetic.coord_pair_count(data)
+    fin = cfg['nf'] + cfg['ctx'] + 1
+    assert synthetic.split_terms('f16x3', 128, cfg['n_layers'], fin, pairs, pc, nodes) == 3.0
+    t2 = synthetic.split_terms('f16x2', 128, cfg['n_layers'], fin, pairs, pc, nodes)
+    assert 2.0 < t2 < 2.5          # the GCL edge models' second layer is ~80 % of the executed work
+    assert synthetic.flops_executed(128, cfg['n_layers'], fin, pairs, pc, nodes) < synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes)
