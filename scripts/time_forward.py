@@ -9,6 +9,7 @@ ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--layers', type=int, default=6)
 ap.add_argument('--precision', default='f16x3')
 ap.add_argument('--team', default='auto', help="compute units per molecule: 'auto', 1, 2 or 4")
+ap.add_argument('--raw', action='store_true', help='time the bare launches (no flag check / host synchronisation per call)')
 a = ap.parse_args()
 from difflinker_amd import Dynamics, synthetic
 from difflinker_amd.datasets import collate
@@ -24,6 +25,8 @@ z = torch.cat([inp['x'], inp['h']], 2) * inp['fragment_mask'] + torch.randn(B, N
 t = torch.full((B, 1), 0.5, device=dev)
 args = dict(t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'], context=inp['context'])
 try:
+    if a.raw:
+        raise RuntimeError('raw launches requested')
     for _ in range(3):
         dyn.forward(**args)
 except Exception as e:      # knock-out builds may produce NaNs: time the raw launch instead
