@@ -8,6 +8,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--n', type=int, default=50)
 ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--seconds', type=float, default=3.0)
+ap.add_argument('--precision', default='f16x3')
 a = ap.parse_args()
 from difflinker_amd import Dynamics, synthetic
 from difflinker_amd.datasets import collate
@@ -16,6 +17,7 @@ mols = synthetic.fc_molecules(a.batch, a.n, a.n, (3, 12), 9, seed=1, uniform_siz
 inp = {k: v.to(dev) for k, v in synthetic.sampler_inputs(collate(mols)).items()}
 torch.manual_seed(0)
 dyn = Dynamics(3, 9, 1, hidden_nf=128, n_layers=6, norm_constant=1e-6).to(dev)
+dyn.precision = a.precision
 B, N = inp['x'].shape[:2]
 z = torch.cat([inp['x'], inp['h']], 2) * inp['fragment_mask'] + torch.randn(B, N, 12, device=dev) * inp['linker_mask']
 t = torch.full((B, 1), 0.5, device=dev)
@@ -46,5 +48,5 @@ stop[0] = True; th.join()
 ms = ev0.elapsed_time(ev1) / n
 mid = samples[1:-1] or samples
 pw = sum(s[0] for s in mid) / max(1, len(mid)); ck = sum(s[1] for s in mid) / max(1, len(mid))
-print(f'{os.environ.get("DIFFLINKER_HIP_LIB", "product"):>22s} B={B:3d}: forward {ms:.3f} ms, power {pw:6.0f} W, sclk {ck:5.0f} MHz, '
+print(f'{os.environ.get("DIFFLINKER_HIP_LIB", "product"):>22s} {a.precision} B={B:3d}: forward {ms:.3f} ms, power {pw:6.0f} W, sclk {ck:5.0f} MHz, '
       f'energy/forward {pw * ms / 1e3:.3f} J ({len(mid)} samples)')
