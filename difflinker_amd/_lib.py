@@ -12,9 +12,11 @@ import torch  # noqa: F401  (loads PyTorch-ROCm's libamdhip64 first so both shar
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DIFFLINKER_HIP_LIB: load another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get('DIFFLINKER_HIP_LIB') or os.path.join(_HERE, 'libdifflinker_hip.so')
+# the same sources compiled with -DDL_TEST_HOOKS (fault injection for tests/test_gpu_team.py); never loaded by the package itself
+TEST_HOOKS_LIB_PATH = os.path.join(_HERE, 'libdifflinker_hip_testhooks.so')
 
 DL_OK = 0
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRECISIONS = {'fp32': 0, 'f16x3': 1, 'f16x2': 2}
 DL_ERR_TOO_MANY_ATOMS = -3
 
@@ -68,7 +70,8 @@ EXPORTS = ('dl_abi_version', 'dl_last_hip_error', 'dl_max_atoms', 'dl_error_stri
            'dl_set_profile_buffer', 'dl_profile_max_events', 'dl_pocket_workspace_bytes', 'dl_egnn_forward_pocket',
            'dl_size_model_num_tensors', 'dl_size_model_create', 'dl_size_model_destroy', 'dl_size_max_fragment_atoms',
            'dl_size_gnn_forward', 'dl_philox_fill', 'dl_egnn_forward_fc_large', 'dl_inpaint_step', 'dl_workspace_bytes',
-           'dl_team_max', 'dl_egnn_forward_fc_team', 'dl_team_max_atoms', 'dl_debug_team_fault')
+           'dl_team_max', 'dl_egnn_forward_fc_team', 'dl_team_max_atoms')
+TEST_HOOK_EXPORTS = ('dl_debug_team_fault',)       # declared under #ifdef DL_TEST_HOOKS: the test-hooks build only
 
 _lib = None
 
@@ -80,16 +83,41 @@ class HipLibraryError(RuntimeError):
 def load():
     """Load the HIP library (once).  Raises ``HipLibraryError`` when it has not been built."""
     global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if _lib is None:
+        _lib = _open(LIB_PATH)
+    return _lib
+
+
+class test_hooks:
+    """Context manager for the fault-injection tests: inside it ``load()`` returns the ``-DDL_TEST_HOOKS`` build of the
+    library (``dl_debug_team_fault`` exists there and nowhere else).  Handles (``dl_model``) are plain structs of device
+    pointers and work across the two builds, but the tests create their models inside the context anyway."""
+
+    def __enter__(self):
+        global _lib
+        self.saved = _lib
+        lib = _open(TEST_HOOKS_LIB_PATH)
+        lib.dl_debug_team_fault.restype = None
+        lib.dl_debug_team_fault.argtypes = [ctypes.c_int32]
+        _lib = lib
+        return lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib.dl_debug_team_fault(0)
+        _lib = self.saved
+        return False
+
+
+def _open(path):
+    if not os.path.exists(path):
         raise HipLibraryError(
-            f'{LIB_PATH} not found: build the HIP extension first '
+            f'{path} not found: build the HIP extension first '
             '(python -c "import __graft_entry__ as g; g.build()"). There is no CPU fallback.')
     try:
-        lib = ctypes.CDLL(LIB_PATH)
+        lib = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover
-        raise HipLibraryError(f'cannot load {LIB_PATH}: {e}') from e
+        raise HipLibraryError(f'cannot load {path}: {e}') from e
     vp, i32 = ctypes.c_void_p, ctypes.c_int32
     lib.dl_abi_version.restype = i32
     lib.dl_last_hip_error.restype = i32
@@ -112,8 +140,6 @@ def load():
     lib.dl_team_max.argtypes = [i32]
     lib.dl_team_max_atoms.restype = i32
     lib.dl_team_max_atoms.argtypes = [i32]
-    lib.dl_debug_team_fault.restype = None
-    lib.dl_debug_team_fault.argtypes = [i32]
     lib.dl_sampler_step.restype = i32
     lib.dl_sampler_step.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, DLStepCoef, vp, vp]
     lib.dl_set_profile_buffer.restype = None
@@ -140,7 +166,6 @@ def load():
     lib.dl_size_max_fragment_atoms.restype = i32
     lib.dl_size_gnn_forward.restype = i32
     lib.dl_size_gnn_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    _lib = lib
     return lib
 
 

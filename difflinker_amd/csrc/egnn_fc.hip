@@ -361,8 +361,12 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
         // step in ~8.1 K ticks beside waves 4-7 (~14 K), leave the loop after 65 % of a pass and wait at the barrier while their
         // partners finish alone - one wave per SIMD, at half the machine's rate (profiles/r04/wave_timeline.log).  Each wave
         // publishes its step count and, at every step, takes the higher priority when it is not ahead of its partner.
-        int* prog = reinterpret_cast<int*>(v.A - L_A + L_PROG);
-        if (lane == 0) prog[w] = 0;
+        // (the two waves of a SIMD are w and w ^ 4: a workgroup's waves are dealt to the four SIMDs round-robin - observed, not
+        // architected; a different mapping would only make the hint useless.  The slots are read and written through a
+        // volatile LDS pointer - nothing may be cached in a register across steps - and are zero when a pass starts: cleared
+        // at kernel entry and again behind the barrier that ends every loop)
+        typedef volatile __attribute__((address_space(3))) int* lds_vint_t;
+        lds_vint_t prog = (lds_vint_t)(reinterpret_cast<int*>(v.A - L_A + L_PROG));
 
         for (int t = 0; t < q; ++t) {
             // the P row, the bias vectors and all of W2' do not depend on t: without an opaque offset the compiler hoists
@@ -676,6 +680,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
     __builtin_amdgcn_s_setprio(0);
     prof_event(pf, w, lane, EQUIV ? 121 : 120);       // (diagnostics builds) this wave left the loop; the barrier follows
     lds_barrier();                         // every wave left the loop: P (v.A), Q (v.B), v.W are dead -> partial sums
+    if (lane == 0) reinterpret_cast<int*>(v.A - L_A + L_PROG)[w] = 0;      // progress slots: zero for the next pass (nobody reads them before its loop)
     if (slot_ok) {
         if (!EQUIV) {
 #pragma unroll
@@ -1404,6 +1409,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
+    if (tid < 8) reinterpret_cast<int*>(v.A - L_A + L_PROG)[tid] = 0;      // pair-loop progress slots (pair_phase); barriers follow
     prof_event(pf, w, lane, 1);
     if (PREC != 0) {
         if (tid < 8) v.fmax[tid] = 0u;
@@ -1899,14 +1905,22 @@ __global__ void sampler_step_kernel(int total, int D, const float* __restrict__ 
 // Host side: weight packing and the C ABI
 // ---------------------------------------------------------------------------------------------------
 thread_local int g_last_hip = 0;
+#ifdef DL_TEST_HOOKS
 std::atomic<int> g_team_fault{0};          // tests only (dl_debug_team_fault): that many of the NEXT team launches fail (member 1 gives up at once)
+#endif
 unsigned long long* g_prof_buf = nullptr;   // diagnostics only (dl_set_profile_buffer)
 
 // one injected failure per team launch while the counter is positive (it cannot stay on by accident: ADVICE round 3)
+// (the product library has no such switch: the hook exists in -DDL_TEST_HOOKS builds only - libdifflinker_hip_testhooks.so,
+// loaded by tests/test_gpu_team.py alone)
 inline int take_team_fault() {
+#ifdef DL_TEST_HOOKS
     int n = g_team_fault.load();
     while (n > 0 && !g_team_fault.compare_exchange_weak(n, n - 1)) {}
     return n > 0 ? 1 : 0;
+#else
+    return 0;
+#endif
 }
 
 inline bool hip_ok(hipError_t e) {
@@ -2074,7 +2088,9 @@ int32_t dl_profile_max_events(void) { return 0; }      // the phase timeline exi
 void dl_set_profile_buffer(void* device_buf) { g_prof_buf = static_cast<unsigned long long*>(device_buf); }
 int32_t dl_last_hip_error(void) { return g_last_hip; }
 int32_t dl_max_atoms(void) { return NMAX; }
+#ifdef DL_TEST_HOOKS
 void dl_debug_team_fault(int32_t launches) { g_team_fault.store(launches < 0 ? 0 : launches); }
+#endif
 
 const char* dl_error_string(int32_t s) {
     switch (s) {

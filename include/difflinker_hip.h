@@ -55,7 +55,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 6
+#define DL_ABI_VERSION 7
 
 typedef enum dl_status {
     DL_OK = 0,
@@ -248,9 +248,13 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* s
  * dl_egnn_forward_fc_large).  With team > 1 the entry points zero nan_flags (and set nan_step to -1) on `stream` themselves. */
 int32_t dl_team_max(int32_t B);
 int32_t dl_team_max_atoms(int32_t team);
-/* tests only: member 1 of every team of the NEXT `launches` team launches gives up at its first exchange (exercises the
- * fail-together path above); the count runs down by itself - the switch cannot stay on by accident - and 0 clears it */
+#ifdef DL_TEST_HOOKS
+/* TEST BUILDS ONLY (-DDL_TEST_HOOKS: difflinker_amd/libdifflinker_hip_testhooks.so, built beside the product library and loaded
+ * by the fault-injection tests alone; the product library does not export it).  Member 1 of every team of the NEXT `launches`
+ * team launches gives up at its first exchange (exercises the fail-together path above); the count runs down by itself - the
+ * switch cannot stay on by accident - and 0 clears it */
 void dl_debug_team_fault(int32_t launches);
+#endif
 /* dl_egnn_forward_fc with a team per molecule (team = 1: identical to dl_egnn_forward_fc) */
 int32_t dl_egnn_forward_fc_team(const dl_model* m, int32_t B, int32_t N, const float* xh, const float* t,
                                 int32_t t_is_scalar, const int8_t* node_mask, const float* linker_mask,

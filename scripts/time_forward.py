@@ -9,6 +9,7 @@ ap.add_argument('--batch', type=int, default=256)
 ap.add_argument('--layers', type=int, default=6)
 ap.add_argument('--precision', default='f16x3')
 ap.add_argument('--team', default='auto', help="compute units per molecule: 'auto', 1, 2 or 4")
+ap.add_argument('--iters', type=int, default=20)
 ap.add_argument('--raw', action='store_true', help='time the bare launches (no flag check / host synchronisation per call)')
 a = ap.parse_args()
 from difflinker_amd import Dynamics, synthetic
@@ -37,8 +38,8 @@ except Exception as e:      # knock-out builds may produce NaNs: time the raw la
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
-for _ in range(20):
+for _ in range(a.iters):
     dyn.forward(**args)
 ev1.record()
 torch.cuda.synchronize()
-print(f'{os.environ.get("DIFFLINKER_HIP_LIB", "product")}: forward (B={B}, n={a.n}, L={a.layers}, {a.precision}, team {dyn.team_for(B)}): {ev0.elapsed_time(ev1) / 20:.3f} ms')
+print(f'{os.environ.get("DIFFLINKER_HIP_LIB", "product")}: forward (B={B}, n={a.n}, L={a.layers}, {a.precision}, team {dyn.team_for(B)}): {ev0.elapsed_time(ev1) / a.iters:.3f} ms')

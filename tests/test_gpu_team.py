@@ -135,16 +135,17 @@ def test_a_team_that_cannot_assemble_fails_together_and_the_call_is_rerun_withou
     member whose team-mates never became resident would after its spin limit: it publishes the poison arrival word, every
     other member stops waiting too, ALL of them end with flag bit 3 (raw C ABI), and the Python drop-in re-runs the batch on
     one compute unit per molecule - the caller sees the oracle's numbers and no exception."""
-    import ctypes
     from difflinker_amd import _lib
-    lib = _lib.load()
+    assert not hasattr(_lib.load(), 'dl_debug_team_fault'), 'the product library must not export the test hook'
     nf = 9
     dyn, sd, cfg = make_dynamics(nf, 1, 2, seed=31)
     inp, z, t = ragged_inputs([20, 33, 9, 50], [4, 6, 2, 9], nf, seed=17)
     ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
     dyn.team = 4
-    lib.dl_debug_team_fault(3)          # the three team launches below fail (the count runs down by itself)
-    try:
+    # the hook lives in the -DDL_TEST_HOOKS build of the library only (libdifflinker_hip_testhooks.so): inside this context the
+    # package's launches go through that build
+    with _lib.test_hooks() as lib:
+        lib.dl_debug_team_fault(3)          # the three team launches below fail (the count runs down by itself)
         prep = dyn.prepare(inp['node_mask'].to(dev()), inp['linker_mask'].to(dev()), inp['edge_mask'].to(dev()), inp['context'].to(dev()))
         out, flags = dyn.launch(prep, t.to(dev()), z.to(dev()))
         torch.cuda.synchronize()
@@ -154,8 +155,6 @@ def test_a_team_that_cannot_assemble_fails_together_and_the_call_is_rerun_withou
         # the fused chain too (same draws in both runs: the bank is fixed before the first launch)
         got, want, cinp = chain_case(nf=9, n_layers=2, sizes=[22, 35], linkers=[5, 7], T=20, keep=1, seed=33, team=2)
         check_chain('chain, team fault -> rerun', got, want, cinp)
-    finally:
-        lib.dl_debug_team_fault(0)
 
 
 @pytest.mark.parametrize('precision', ['f16x3', 'fp32'])

@@ -21,12 +21,17 @@ def test_library_loads_and_exports_every_declared_symbol():
     from difflinker_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'difflinker_hip.h')).read()
-    declared = set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', header))
-    declared -= {'dl_max_atoms'} - {'dl_max_atoms'}
+    product, hooks = re.split(r'#ifdef DL_TEST_HOOKS', header)[0::2], re.findall(r'#ifdef DL_TEST_HOOKS(.*?)#endif', header, re.S)
+    declared = set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', re.sub(r'#ifdef DL_TEST_HOOKS.*?#endif', '', header, flags=re.S)))
+    hooked = set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', ' '.join(hooks)))
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
+    assert hooked == set(_lib.TEST_HOOK_EXPORTS), (hooked ^ set(_lib.TEST_HOOK_EXPORTS))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.dl_abi_version() == _lib.ABI_VERSION == 6
+    for name in hooked:                      # test hooks: in the -DDL_TEST_HOOKS build only, never in the product library
+        assert not hasattr(lib, name), f'{name} exported by the product library'
+        assert hasattr(ctypes.CDLL(_lib.TEST_HOOKS_LIB_PATH), name), name
+    assert lib.dl_abi_version() == _lib.ABI_VERSION == 7
     # the caller-owned scratch (ABI v6): a size query, no device needed; nothing for an empty batch, linear in the batch,
     # a team adds its exchange rows and arrival words on top of one h-row block per workgroup
     w1, w2 = lib.dl_workspace_bytes(1, 1), lib.dl_workspace_bytes(2, 1)
