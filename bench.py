@@ -66,6 +66,8 @@ def parse():
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the secondary measurements (exact-fp32 mode, C4 pockets, other batch sizes) of the N=1 line')
     ap.add_argument('--precision', default=None, choices=['f16x3', 'fp32', 'f16x2'], help='arithmetic mode (default: f16x3)')
+    ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)     # the profiled child of measure_traffic()
+    ap.add_argument('--no-traffic', action='store_true', help='skip the two rocprofv3 --pmc passes behind roofline.traffic')
     return ap.parse_args()
 
 
@@ -100,18 +102,53 @@ def pocket_edge_count(inp, cutoff_cross=10.0):
     return int(adj.sum()), int(into_linker.sum())
 
 
+REFERENCE_ROOT = '/root/reference'     # the unmodified reference: present in the build container, absent on the GPU box
+
+
+def reference_forward(edm, cfg):
+    """``Dynamics.forward`` of the UNMODIFIED reference (src/egnn.py:374-447 / :471-552) with this model's weights, or None
+    where the reference tree does not exist (the GPU box: the oracle port - the same numbers to the bit, 4 % apart in time,
+    profiles/r04/cpu_reference_vs_port.log - is timed instead)."""
+    if not os.path.isfile(os.path.join(REFERENCE_ROOT, 'src', 'egnn.py')):
+        return None
+    try:
+        sys.dont_write_bytecode = True                         # the reference tree is read-only
+        sys.path.insert(0, REFERENCE_ROOT)
+        from src import egnn as ref_egnn
+        pockets = cfg['graph_type'] != 'FC'
+        cls = ref_egnn.DynamicsWithPockets if pockets else ref_egnn.Dynamics
+        ref = cls(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128, device='cpu', n_layers=cfg['n_layers'],
+                  attention=False, tanh=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False, normalization_factor=100,
+                  aggregation_method='sum', model='egnn_dynamics', normalization='batch_norm', centering=False,
+                  graph_type=cfg['graph_type'])
+        ref.load_state_dict({k: v.detach().cpu().clone() for k, v in edm.dynamics.state_dict().items()}, strict=True)
+        ref.eval()
+        return lambda sd, ocfg, t, z, nm, lm, em, ctx: ref.forward(t=t, xh=z, node_mask=nm, linker_mask=lm, edge_mask=em, context=ctx)
+    except Exception as e:                                     # a reference tree that does not import here: the port
+        print(f'note: the reference modules under {REFERENCE_ROOT} could not be used ({type(e).__name__}: {e}); timing the port',
+              file=sys.stderr)
+        return None
+    finally:
+        if sys.path and sys.path[0] == REFERENCE_ROOT:
+            sys.path.pop(0)
+
+
 def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
-    """Oracle = PyTorch-CPU port of the reference path on the host cores, bounded sample: the first
-    `sample_batch` molecules of the same batch, best of a few thread counts (PyTorch CPU ops stop scaling
-    well before a many-core host is full), scaled linearly to the whole batch and to T+1 forwards
-    (per-edge cost is constant; every step costs the same)."""
+    """The reference path on the host cores, bounded sample: the first `sample_batch` molecules of the same batch, best of a
+    few thread counts (PyTorch CPU ops stop scaling well before a many-core host is full), scaled linearly to the whole
+    batch and to T+1 forwards (per-edge cost is constant; every step costs the same).  What is timed: the unmodified
+    reference modules where /root/reference exists (``kind: "reference"``), else the oracle = the PyTorch-CPU port of the
+    same op sequence (``kind: "port"``)."""
     from oracle import egnn_oracle
     cores = os.cpu_count() or 1
     sd = {k: v.detach().cpu().clone() for k, v in edm.dynamics.state_dict().items()}
     pockets = cfg['graph_type'] != 'FC'
     ocfg = egnn_oracle.EGNNConfig(in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], n_layers=cfg['n_layers'],
                                   graph_type=cfg['graph_type'])
-    forward = egnn_oracle.dynamics_forward_pockets if pockets else egnn_oracle.dynamics_forward
+    forward = reference_forward(edm, cfg)
+    kind = 'reference' if forward is not None else 'port'
+    if forward is None:
+        forward = egnn_oracle.dynamics_forward_pockets if pockets else egnn_oracle.dynamics_forward
     B, N = inp['x'].shape[:2]
     b = min(8 if pockets else sample_batch, B)
     g = torch.Generator().manual_seed(1)
@@ -134,11 +171,56 @@ def cpu_baseline(edm, cfg, inp, n_forwards, sample_batch=32):
     dt, threads = best
     fwd_full = dt * B / b
     chain_s = fwd_full * (cfg['T'] + 1)
-    return {'value': B / chain_s, 'unit': 'molecules/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_forwards} Dynamics.forward calls on the first {b} of the {B} molecules (N={N}, '
+    what = 'Dynamics.forward calls of the unmodified reference (src/egnn.py)' if kind == 'reference' else \
+        'Dynamics.forward calls of the oracle port (the reference\'s op sequence on PyTorch-CPU; /root/reference is absent here)'
+    return {'value': B / chain_s, 'unit': 'molecules/s', 'cores': threads, 'kind': kind,
+            'sample': f'{n_forwards} {what} on the first {b} of the {B} molecules (N={N}, '
                       f'L={cfg["n_layers"]}) after 1 warm-up, best of 8/16/32/64 threads ({threads}): {dt:.2f} s each; '
                       f'scaled x{B / b:g} to the batch and x{cfg["T"] + 1} to the chain; host has {cores} logical cores',
             's_per_forward_full_batch': fwd_full}
+
+
+def measure_traffic(a, cfg, child_T=50):
+    """Fabric-side bytes per launch of the dominant kernel, MEASURED BY THIS RUN (round 4 read them from a
+    committed file): two extra ``rocprofv3 --pmc`` passes (FETCH_SIZE, then WRITE_SIZE - they do not fit one pass,
+    MI355X_MICROARCH.md) over a child process that samples the same batch with T = `child_T`, after the timed region.  The
+    per-forward figure (every forward costs the same) is scaled to the T + 1 forwards of the benchmarked launch; FETCH_SIZE is
+    doubled (gfx950 tallies 128-byte requests as 64) and both are KiB.  Returns (bytes per launch or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'not measured: rocprofv3 is not on PATH'
+    per_forward = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out_dir = tempfile.mkdtemp(prefix=f'dl_pmc_{counter}_', dir='/tmp')
+        cmd = ['rocprofv3', '--pmc', counter, '-d', out_dir, '--output-format', 'csv', '--', sys.executable, os.path.abspath(__file__),
+               '--traffic-child', '--config', a.config, '--T', str(child_T), '--noise', a.noise, '--steps', '1', '--warmup', '1',
+               '--no-secondary', '--no-cpu-baseline'] + (['--batch', str(a.batch)] if a.batch is not None else []) + \
+              (['--precision', a.precision] if a.precision else []) + (['--uniform-size'] if a.uniform_size else [])
+        env = dict(os.environ, TMPDIR='/tmp')
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            vals = []
+            for path in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if 'sample_chain_fc_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                        vals.append(float(r['Counter_Value']))
+            if not vals:
+                return None, f'not measured: the {counter} pass recorded no launch of sample_chain_fc_kernel'
+            per_forward[counter] = sum(vals) / len(vals) * 1024.0 / (child_T + 1)
+        except Exception as e:
+            return None, f'not measured: the rocprofv3 --pmc {counter} pass failed ({type(e).__name__})'
+        finally:
+            shutil.rmtree(out_dir, ignore_errors=True)
+    fetch, write = 2.0 * per_forward['FETCH_SIZE'], per_forward['WRITE_SIZE']
+    total = (fetch + write) * (cfg['T'] + 1)
+    return total, (f'measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) over a child process sampling the same '
+                   f'batch with T = {child_T}; per forward {fetch / 1e6:.0f} MB fetched (FETCH_SIZE x2, gfx950) + {write / 1e6:.0f} MB '
+                   f'written, x{cfg["T"] + 1} forwards; fabric-side, Infinity-Cache hits included (the T0 / residual tiles a '
+                   f'workgroup parks in its HBM scratch and the weights every XCD streams); the algorithmic bytes are ~2 MB per forward')
 
 
 def time_chains(edm, inp, steps=1, warmup=1):
@@ -379,23 +461,18 @@ def main():
                 'issue port its VALU, transcendental and matrix instructions share (profiles/r04), see DESIGN.md'
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
-        # fabric-side bytes per launch: NOT measured in this run (rocprofv3 --pmc passes cannot run inside the timed
-        # process) but taken from the committed counter passes of the same launch (profiles/r04/pmc_chain_kernel_T500.json,
-        # collected by scripts/profile_gpu.sh on this command line; FETCH_SIZE doubled for gfx950) - labelled as such
-        traffic, traffic_note = None, None
-        pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r04', 'pmc_chain_kernel_T500.json')
-        if not pockets and precision == 'f16x3' and a.config == 'C2' and not a.uniform_size and os.path.exists(pmc_path):
-            d_ = json.load(open(pmc_path))['_derived']
-            per_fwd = (d_['hbm_fetch_bytes_per_launch_x2_corrected'] + d_['hbm_write_bytes_per_launch']) / float(d_['forwards_per_launch'])
-            traffic = per_fwd * (cfg['T'] + 1) * (B / 256.0)
-            traffic_note = 'from_profile: FETCH_SIZE x2 + WRITE_SIZE of profiles/r04/pmc_chain_kernel_T500.json (the same launch, ' \
-                           'separate rocprofv3 --pmc passes); fabric-side, Infinity-Cache hits included (scratch + weight ' \
-                           'streaming); algorithmic HBM bytes are ~2 MB per forward'
+        # fabric-side bytes per launch of the dominant kernel: two rocprofv3 --pmc passes of a T = 50 child, outside the timed
+        # region (measure_traffic); null with the reason when they could not run
+        traffic, traffic_note = None, 'not measured (pocket path: many kernels per chain; multi-rank runs; --no-traffic)'
+        if not pockets and world == 1 and not a.no_traffic and not a.traffic_child:
+            traffic, traffic_note = measure_traffic(a, cfg)
+        DTYPES = {'f16x3': 'f32 (f16x3 split MFMA, fp32 accumulate)', 'fp32': 'f32',
+                  'f16x2': 'f32 (f16x2 / f16x3 split MFMA, fp32 accumulate)'}
         out = {
             'metric': 'molecules/sec (500-step sample_chain)', 'value': Bg * a.steps / elapsed,
             'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': 1e3 * elapsed / a.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'precision': precision, 'data': 'synthetic', 'noise': edm.noise_source,
+            'vs_baseline': None, 'dtype': DTYPES[precision], 'precision': precision, 'data': 'synthetic', 'noise': edm.noise_source,
             'config': {'workload': f'{a.config}: {"GEOM geom_difflinker" if not pockets else "pockets_difflinker_full_no_anchors_fc (FC-10A-4A radius graph)"} hparams (egnn_dynamics, hidden 128, '
                                    f'{cfg["n_layers"]} blocks), batch={B} molecules/GPU padded to N={N} '
                                    f'(n_b {"= N" if a.uniform_size else ("~ U{35..50}" if not pockets else "30 fragment + 250 pocket + 6..12 linker atoms")}), T={cfg["T"]} reverse steps '
@@ -425,6 +502,9 @@ def main():
                           'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '
                                   'LDS-resident for the whole chain, so the HBM fraction is << 1 % by design'},
         }
+        if a.traffic_child:                                 # the profiled child of measure_traffic(): the launches are all it is for
+            return
+        # the optional companions must not cost the line: an error in one of them is recorded, not raised
         if world == 1 and not a.no_secondary and a.config == 'C2' and not a.uniform_size and a.batch is None and a.T is None:
             out['secondary'] = secondary_measurements(device, a)
             # the library's default noise source is the reference's torch.randn call sequence (EDM.noise_source = 'torch'): its
@@ -434,8 +514,12 @@ def main():
                 out['value_by_noise_source'] = {'philox (in-kernel, this line)': out['value'],
                                                 'torch (reference randn stream, library default)': tn[0]['molecules_per_s']}
         if world == 1 and not a.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(edm, cfg, inp_cpu, a.cpu_forwards)
-            out['eager_rocm_baseline'] = eager_rocm_baseline(edm, cfg, inp_cpu, device)
+            for key, fn in (('cpu_baseline', lambda: cpu_baseline(edm, cfg, inp_cpu, a.cpu_forwards)),
+                            ('eager_rocm_baseline', lambda: eager_rocm_baseline(edm, cfg, inp_cpu, device))):
+                try:
+                    out[key] = fn()
+                except Exception as e:
+                    out[key] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

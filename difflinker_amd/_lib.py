@@ -61,7 +61,7 @@ class DLChainArgs(ctypes.Structure):
         ('norm_x', ctypes.c_float), ('norm_h', ctypes.c_float), ('bias_h', ctypes.c_float),
         ('chain', ctypes.c_void_p), ('nan_flags', ctypes.c_void_p), ('nan_step', ctypes.c_void_p),
         ('order', ctypes.c_void_p), ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-        ('mol_index', ctypes.c_void_p),
+        ('mol_index', ctypes.c_void_p), ('order_first', ctypes.c_int32), ('order_count', ctypes.c_int32),
     ]
 
 

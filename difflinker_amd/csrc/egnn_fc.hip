@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <vector>
 
 #include "../../include/difflinker_hip.h"
 #include "pack_layout.h"
@@ -171,6 +172,13 @@ __device__ __forceinline__ void block_max(unsigned* slot, float val, int lane) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // every global load / LDS-DMA this wave issued has landed (call before the barrier that publishes DMA data)
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Uniform scalars of the packed weights (scales, bounds) through the SCALAR cache: a vector load of them would queue behind
+// every fragment prefetch and LDS-DMA in flight (vector memory returns in order) - s_load does not.
+__device__ __forceinline__ float cload(const float* p, int k) {
+    typedef const __attribute__((address_space(4))) float* cptr_t;
+    return reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p))[k];
+}
 
 // LDS-DMA (global_load_lds_dwordx4: global -> LDS without staging registers, 1 KB per wave instruction) of the
 // [k][c][nt] image of a 128x128 matrix into v.W and of the four 128-vectors at `vecs` into v.vec (a GCL uses three;
@@ -324,7 +332,12 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
         const float* Pp_ = v.A + li * LDH + 4 * hh;
         const float* bias_p_ = v.vec + 2 * HID + 4 * hh;
         const float* w7_p_ = v.vec + 3 * HID + 4 * hh;
-        const float isa = inv_pow2(sa);
+        // the hidden features of k-slab s enter the second layer times sa * 2^n_s (balanced packing: the columns of W2' carry 2^-n_s)
+        float isa_s[8];
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_)
+            isa_s[s_] = (PREC == 0) ? 1.0f
+                : __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(inv_pow2(sa * cload(sc, (EQUIV ? ES_NE : GS_NE) + s_)))));
 
         // rank-2 geometric term wr'[f] r + wd'[f] d0 as an MFMA: k-slots of half 0 carry r, of half 1 carry d0
         float ga[4];                 // fp32: A operand (k = hh)
@@ -544,8 +557,9 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     yy[0] = fmaf(g1[2 * e], invS1, p0); yy[1] = fmaf(g1[2 * e + 1], invS1, p1);
                     ee[0] = __builtin_amdgcn_exp2f(yy[0]); ee[1] = __builtin_amdgcn_exp2f(yy[1]);
                 };
-                auto chunk_b = [&]() {
-                    // SiLU in u-form, scaled into the fp16 range: y * sa / (1 + 2^y)
+                auto chunk_b = [&](int ge) {
+                    // SiLU in u-form, scaled into the fp16 range: y * (sa 2^n) / (1 + 2^y), n = the exponent of the element's k-slab
+                    const float isa = isa_s[(ge >> 2) & 7];
                     ee[0] = __builtin_amdgcn_rcpf(fmaf(ee[0], isa, isa)); ee[1] = __builtin_amdgcn_rcpf(fmaf(ee[1], isa, isa));
                 };
                 auto chunk_c = [&](int ge) {
@@ -590,7 +604,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
 #pragma unroll
                 for (int ge = 0; ge < 4; ++ge) {
                     if ((ge & 1) == 0) load_pq((ge >> 1) + 1);
-                    chunk_a(ge); chunk_b(); chunk_c(ge);
+                    chunk_a(ge); chunk_b(ge); chunk_c(ge);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 loop_event(pf, w, lane, 51);
@@ -617,7 +631,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                                 for (int k = (3 * i) / 2; k < (3 * (i + 1)) / 2; ++k) {
                                     const int ge = 4 * (s + 1) + k / 3, ph = k % 3;
                                     if (ph == 0) { if ((ge & 1) == 0 && (ge >> 1) + 1 < 16) load_pq((ge >> 1) + 1); chunk_a(ge); }
-                                    if (ph == 1) chunk_b();
+                                    if (ph == 1) chunk_b(ge);
                                     if (ph == 2) chunk_c(ge);
                                 }
                             }
@@ -643,7 +657,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                         if (i == 10 && s < 6 && !(s & 1)) g1 = mfma_h(gaf[(s + 2) >> 1], xf, Qc);
                         if (s < 7) {
                             if (ph == 0) { if ((ge & 1) == 0 && (ge >> 1) + 1 < 16) load_pq((ge >> 1) + 1); chunk_a(ge); }
-                            if (ph == 1) chunk_b();
+                            if (ph == 1) chunk_b(ge);
                             if (ph == 2) chunk_c(ge);
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -871,12 +885,6 @@ __device__ __forceinline__ void tile_load16(const float* tiles, int t, int lane,
     }
 }
 
-// Uniform scalars of the packed weights (scales, bounds) through the SCALAR cache: a vector load of them would queue behind
-// every fragment prefetch and LDS-DMA in flight (vector memory returns in order) - s_load does not.
-__device__ __forceinline__ float cload(const float* p, int k) {
-    typedef const __attribute__((address_space(4))) float* cptr_t;
-    return reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p))[k];
-}
 constexpr int FS_HS = 7;                      // v.fmax slot: scale the h fragment rows in v.C were written with (float bits)
 // host-computed bounds in the scale block of a GCL / equivariant update (pack_layout.h: G_SCALE / E_SCALE)
 constexpr int SC_L1_W1A = 12, SC_L1_W1B = 13, SC_L1_W3A = 14, SC_L1_W3B = 15, SC_L1_W4 = 16, SC_B1 = 17, SC_B3 = 18, SC_B4 = 19;
@@ -1035,8 +1043,9 @@ __device__ __forceinline__ void pre_phase(const Lds& v, int nown, int w, int lan
             const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
             S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(sc, 6)), scale_for(4.0f * x02) * scale_for(cload(sc, 7)));
         }
-        inv = inv_pow2(s_hf * cload(sc, half)) * S1;
-        if (GCLP) inv3 = inv_pow2(s_hf * cload(sc, 2));
+        // weight scales: one per 32-feature output tile (balanced packing, pack_layout.h)
+        inv = inv_pow2(s_hf * cload(sc, (GCLP ? GS_SW_W1A : ES_SW_W5A) + 4 * half + nt)) * S1;
+        if (GCLP) inv3 = inv_pow2(s_hf * cload(sc, GS_SW_W3A + nt));
     }
     const int mtiles = nown > 32 ? 2 : 1;
     AReg a;
@@ -1173,7 +1182,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);     // senders: any atom of the molecule
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);            // >= |P_i| + |Q_j|
-        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
+        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, GS_WRW) + x02 * cload(sc, GS_WDW)));        // (bounds with the slab exponents applied)
         accs = sa * cload(sc, 5);
     }
     // (edge attention is a KERNEL variant, not a branch: its pair loop keeps the 64 messages of a step until the logit is known
@@ -1227,7 +1236,9 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     const float y3b = cload(sc, SC_L1_W3A) * hmax + cload(sc, SC_L1_W3B) * aggmax + cload(sc, SC_B3);
     const float s_t = (PREC != 0) ? scale_for(y3b) : 1.0f;
     const float s_hn = (PREC != 0) ? scale_for(hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4)) : 1.0f;
-    const float inv1 = (PREC != 0) ? inv_pow2(s_agg * cload(sc, 3)) : 1.0f, inv2 = (PREC != 0) ? inv_pow2(s_t * cload(sc, 4)) : 1.0f;
+    // (W3b': one weight scale per output tile; the hidden layer t of tile nt is written times s_t * 2^n_nt, W4' carries 2^-n per column)
+    const float inv1 = (PREC != 0) ? inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)) : 1.0f, inv2 = (PREC != 0) ? inv_pow2(s_t * cload(sc, 4)) : 1.0f;
+    const float s_tn = (PREC != 0) ? s_t * cload(sc, GS_NT + nt) : 1.0f;
     prof_event(pf, w, lane, 23);
     lds_barrier();
     prof_event(pf, w, lane, 14);
@@ -1251,7 +1262,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         for (int reg = 0; reg < 16; ++reg) {
             const int row = 32 * mt + acc_row(reg, hh);
             const float tval = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, t0r[reg]));
-            put_elem<PREC>(row < nown ? v.B + row * LDH : v.dummy, 32 * nt + c, tval, s_t);
+            put_elem<PREC>(row < nown ? v.B + row * LDH : v.dummy, 32 * nt + c, tval, s_tn);
         }
     }
     prof_event(pf, w, lane, 15);
@@ -1333,7 +1344,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
-        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, 6) + x02 * cload(sc, 7)));
+        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, ES_WRW) + x02 * cload(sc, ES_WDW)));
         accs = sa * cload(sc, 2);
     }
     pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
@@ -1805,12 +1816,13 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         const dl_chain_args& g = p.a;
         const int tid = threadIdx.x;
         int k = blockIdx.x, rank = 0, S = 1;
+        const int count = g.order_count > 0 ? g.order_count : g.B;        // molecules of THIS launch (a part of the batch, or all of it)
         if constexpr (TEAM) {
             const TeamSlot ts = team_slot(blockIdx.x, g.team);
-            if (ts.slot >= g.B) return;
+            if (ts.slot >= count) return;
             k = ts.slot; rank = ts.rank; S = g.team;
         }
-        const int b = g.order ? g.order[k] : k;
+        const int b = g.order ? g.order[g.order_first + k] : k;
         const int N = g.N, nf = p.md.nf, D = 3 + nf, K = g.keep_frames, B = g.B;
         const int limit = TEAM ? NQMAX : NMAX;
         T = g.T;
@@ -1970,9 +1982,24 @@ inline void split_f16(double v, uint16_t& hi, uint16_t& lo) {
     memcpy(&lo, &l, 2);
 }
 
-// f16x3 node-fragment order: unit[nt][part*8 + slab][lane][e] (fp16), value = part(sw*W'[f = 32nt + (lane&31)][k]),
-// k = 16*slab + 8*(lane>>5) + e; same bytes as the fp32 unit (64 KB), read as 16 x dwordx4 per lane
-double pack_unit_f16(float* dstf, const float* w, int ld, int col0, double scale) {
+// f16x3 node-fragment order: unit[nt][part*8 + slab][lane][e] (fp16), value = part(sw[nt]*W'[f = 32nt + (lane&31)][k]),
+// k = 16*slab + 8*(lane>>5) + e; same bytes as the fp32 unit (64 KB), read as 16 x dwordx4 per lane.  One power-of-two scale
+// per 32-row output tile (`sw4`): with the hidden features renumbered by magnitude (balance_hidden) the rows of a tile are of
+// one size class, and a small row no longer sits tens of binades below a matrix-wide maximum
+inline double f16_tile_scale(const float* w, int ld, int col0, int row0, double scale) {
+    double m = 0.0;
+    for (int f = row0; f < row0 + 32; ++f)
+        for (int k = 0; k < HID; ++k) m = fmax(m, fabs(double(w[size_t(f) * ld + col0 + k]) * scale));
+    if (!(m > 0.0) || !std::isfinite(m)) return 1.0;
+    int e;
+    frexp(m, &e);                                    // m < 2^e
+    e = 15 - e;
+    if (e > 60) e = 60;
+    if (e < -60) e = -60;
+    return ldexp(1.0, e);
+}
+// (one scale for the whole matrix: W4', whose rows are not renumbered)
+double pack_unit_f16_uniform(float* dstf, const float* w, int ld, int col0, double scale) {
     const double sw = f16_weight_scale(w, ld, col0, HID, scale);
     uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
     for (int nt = 0; nt < 4; ++nt)
@@ -1987,6 +2014,23 @@ double pack_unit_f16(float* dstf, const float* w, int ld, int col0, double scale
                     dst[(((nt * 16 + 8 + slab) * 64 + lane) * 8) + e] = lo;
                 }
     return sw;
+}
+void pack_unit_f16(float* dstf, const float* w, int ld, int col0, double scale, float* sw4) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
+    for (int nt = 0; nt < 4; ++nt) {
+        const double sw = f16_tile_scale(w, ld, col0, 32 * nt, scale);
+        sw4[nt] = float(sw);
+        for (int slab = 0; slab < 8; ++slab)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 32 * nt + (lane & 31);
+                    const int k = 16 * slab + 8 * (lane >> 5) + e;
+                    uint16_t hi, lo;
+                    split_f16(double(w[size_t(f) * ld + col0 + k]) * scale * sw, hi, lo);
+                    dst[(((nt * 16 + slab) * 64 + lane) * 8) + e] = hi;
+                    dst[(((nt * 16 + 8 + slab) * 64 + lane) * 8) + e] = lo;
+                }
+    }
 }
 
 // f16x3 LDS image: img[part*8 + slab][nt][lane][e]
@@ -2075,6 +2119,61 @@ void pack_vec(float* dst, const float* src, int stride, double scale) {
     for (int f = 0; f < HID; ++f) dst[f] = float(double(src[size_t(f) * stride]) * scale);
 }
 
+// ---- balanced packing (f16 modes; pack_layout.h: GS_*).  The hidden features of a two-layer MLP in the order of their
+// magnitude proxy, largest first: perm[p] = original index of the feature at position p; fac[p] = 2^n of its group of `group`
+// consecutive positions, n = how many whole binades the group's largest proxy sits below the overall largest (0 .. 40).
+// `on` = false (exact-fp32 mode): identity, all factors 1 - that mode packs exactly as before.
+struct Balance {
+    int perm[HID];
+    double fac[HID];
+};
+void balance_hidden(Balance& b, const double* proxy, int group, bool on) {
+    for (int p = 0; p < HID; ++p) { b.perm[p] = p; b.fac[p] = 1.0; }
+    if (!on) return;
+    std::stable_sort(b.perm, b.perm + HID, [&](int x, int y) { return proxy[x] > proxy[y]; });
+    const double top = proxy[b.perm[0]];
+    if (!(top > 0.0) || !std::isfinite(top)) return;
+    for (int p0 = 0; p0 < HID; p0 += group) {
+        const double m = proxy[b.perm[p0]];                     // the group's largest
+        int n = 0;
+        if (m > 0.0 && std::isfinite(m)) {
+            int et, em;
+            frexp(top, &et); frexp(m, &em);
+            n = std::min(std::max(et - em, 0), 40);
+        } else n = 40;
+        for (int p = p0; p < p0 + group; ++p) b.fac[p] = ldexp(1.0, n);
+    }
+}
+// rows of a first-layer matrix [128][ld] (and its bias) in the balanced order
+void permute_rows(std::vector<float>& wp, std::vector<float>& bp, const float* w, const float* bias, int ld, const Balance& b) {
+    wp.resize(size_t(HID) * ld); bp.resize(HID);
+    for (int p = 0; p < HID; ++p) {
+        memcpy(&wp[size_t(p) * ld], w + size_t(b.perm[p]) * ld, size_t(ld) * sizeof(float));
+        bp[p] = bias[b.perm[p]];
+    }
+}
+// columns of a second-layer matrix [128][128] in the balanced order, times 2^-n (exact)
+void permute_cols(std::vector<float>& wp, const float* w, const Balance& b) {
+    wp.resize(size_t(HID) * HID);
+    for (int f = 0; f < HID; ++f)
+        for (int p = 0; p < HID; ++p) wp[size_t(f) * HID + p] = float(double(w[size_t(f) * HID + b.perm[p]]) / b.fac[p]);
+}
+// max over output rows of fac[row] * sum_k |scale * W[row][col0 + k]|, k < ncols  (a bound: rounded up)
+float row_l1_weighted(const float* w, int ld, int col0, int ncols, double scale, const Balance& b) {
+    double m = 0.0;
+    for (int p = 0; p < HID; ++p) {
+        double r = 0.0;
+        for (int k = 0; k < ncols; ++k) r += fabs(double(w[size_t(p) * ld + col0 + k]) * scale);
+        m = fmax(m, r * b.fac[p]);
+    }
+    return float(m * 1.0001);
+}
+float vec_absmax_weighted(const float* v, const Balance& b) {
+    double m = 0.0;
+    for (int p = 0; p < HID; ++p) m = fmax(m, fabs(double(v[p])) * b.fac[p]);
+    return float(m * 1.0001);
+}
+
 }  // namespace
 
 extern "C" {
@@ -2136,11 +2235,6 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     float* hp = static_cast<float*>(calloc(total, sizeof(float)));
     if (!hp) return DL_ERR_ALLOC;
     const bool f16 = cfg->precision != DL_PRECISION_FP32;
-    auto unit = [&](float* d, const float* ww, int ld, int col0, double sc) -> float {
-        if (f16) return float(pack_unit_f16(d, ww, ld, col0, sc));
-        pack_unit(d, ww, ld, col0, sc);
-        return 1.0f;
-    };
     auto image = [&](float* d, const float* ww, int ld, double sc) -> float {
         if (f16) return float(pack_lds_image_f16(d, ww, ld, sc));
         pack_lds_image(d, ww, ld, sc);
@@ -2164,6 +2258,8 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         memcpy(hp + OFF_OUT_W + o * HID, ow + size_t(o) * HID, HID * sizeof(float));
         hp[OFF_OUT_B + o] = ob[o];
     }
+    std::vector<float> w1p, b1p, w2p, w3p, b3p, w4p;
+    std::vector<double> proxy(HID);
     for (int blk = 0; blk < L; ++blk) {
         float* base = hp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
         for (int gi = 0; gi < 2; ++gi) {
@@ -2175,35 +2271,73 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             const float* watt = nullptr; const float* batt = nullptr;
             if (cfg->attention) { watt = w[ti++]; batt = w[ti++]; }   // att_mlp.0 [1][128], [1]
             const int ld1 = 2 * HID + (cfg->sin_embedding ? SIN_K : 2);
-            float* sc = g + G_SCALE;
-            sc[0] = unit(g + G_W1A, w1, ld1, 0, c);
-            sc[1] = unit(g + G_W1B, w1, ld1, HID, c);
-            sc[2] = unit(g + G_W3A, w3, 2 * HID, 0, c);
-            // agg arrives as c * true message sum: the 1/normalization_factor of 'sum' is folded here, the 1/N of 'mean'
+            const int nattr = ld1 - 2 * HID;
+            // agg arrives as c * true message sum: the 1/normalization_factor of 'sum' is folded into W3b', the 1/N of 'mean'
             // is applied where the slot partials are added (N is a property of the batch, not of the model)
-            sc[3] = unit(g + G_W3B, w3, 2 * HID, HID, cfg->aggregation_mean ? 1.0 : inv_norm);
-            sc[4] = unit(g + G_W4, w4, HID, 0, 1.0 / c);
-            sc[5] = image(g + G_W2, w2, HID, 1.0);
-            image_t(g + G_W2T, w2, HID, 1.0);
-            float* vv = g + G_VEC;
-            pack_vec(vv + 0 * HID, b1, 1, c);
-            if (!cfg->sin_embedding) {
-                pack_vec(vv + 1 * HID, w1 + 2 * HID, ld1, c);         // radial column
-                pack_vec(vv + 2 * HID, w1 + 2 * HID + 1, ld1, c);     // d0 column
+            const double s3b = cfg->aggregation_mean ? 1.0 : inv_norm;
+            // balanced order of the two hidden layers (f16 modes): the edge model's (rows of W1, columns of W2) in k-slabs of 16,
+            // the node MLP's (rows of W3, columns of W4) in tiles of 32.  Proxy: what the feature's pre-activation can reach for
+            // |h| ~ 1 (the distance columns weighted by a typical squared distance of 32 A^2)
+            Balance be, bt;
+            for (int f = 0; f < HID; ++f) {
+                double r = fabs(double(b1[f]));
+                for (int k = 0; k < 2 * HID; ++k) r += fabs(double(w1[size_t(f) * ld1 + k]));
+                for (int k = 0; k < nattr; ++k) r += (cfg->sin_embedding ? 1.0 : 32.0) * fabs(double(w1[size_t(f) * ld1 + 2 * HID + k]));
+                proxy[f] = r;
+            }
+            balance_hidden(be, proxy.data(), 16, f16);
+            for (int f = 0; f < HID; ++f) {
+                double r = fabs(double(b3[f]) * c);
+                for (int k = 0; k < HID; ++k) r += fabs(double(w3[size_t(f) * 2 * HID + k]) * c) + fabs(double(w3[size_t(f) * 2 * HID + HID + k]) * s3b);
+                proxy[f] = r;
+            }
+            balance_hidden(bt, proxy.data(), 32, f16);
+            permute_rows(w1p, b1p, w1, b1, ld1, be);
+            permute_cols(w2p, w2, be);
+            permute_rows(w3p, b3p, w3, b3, 2 * HID, bt);
+            permute_cols(w4p, w4, bt);
+            float* sc = g + G_SCALE;
+            if (f16) {
+                pack_unit_f16(g + G_W1A, w1p.data(), ld1, 0, c, sc + GS_SW_W1A);
+                pack_unit_f16(g + G_W1B, w1p.data(), ld1, HID, c, sc + GS_SW_W1B);
+                pack_unit_f16(g + G_W3A, w3p.data(), 2 * HID, 0, c, sc + GS_SW_W3A);
+                pack_unit_f16(g + G_W3B, w3p.data(), 2 * HID, HID, s3b, sc + GS_SW_W3B);
+                // W4': its rows are the node features themselves (no renumbering there): one scale for the matrix
+                sc[4] = float(pack_unit_f16_uniform(g + G_W4, w4p.data(), HID, 0, 1.0 / c));
             } else {
-                sc[20] = pack_sin_columns(g + G_WG, w1, ld1, c);      // 24 embedded-distance columns; sc[20] = largest row L1 norm
+                pack_unit(g + G_W1A, w1p.data(), ld1, 0, c); pack_unit(g + G_W1B, w1p.data(), ld1, HID, c);
+                pack_unit(g + G_W3A, w3p.data(), 2 * HID, 0, c); pack_unit(g + G_W3B, w3p.data(), 2 * HID, HID, s3b);
+                pack_unit(g + G_W4, w4p.data(), HID, 0, 1.0 / c);
+                for (int k = 0; k < 16; ++k) sc[GS_SW_W1A + k] = 1.0f;
+                sc[4] = 1.0f;
+            }
+            sc[5] = image(g + G_W2, w2p.data(), HID, 1.0);
+            image_t(g + G_W2T, w2p.data(), HID, 1.0);
+            for (int s_ = 0; s_ < 8; ++s_) sc[GS_NE + s_] = float(be.fac[16 * s_]);
+            for (int nt = 0; nt < 4; ++nt) sc[GS_NT + nt] = float(bt.fac[32 * nt]);
+            float* vv = g + G_VEC;
+            pack_vec(vv + 0 * HID, b1p.data(), 1, c);
+            if (!cfg->sin_embedding) {
+                pack_vec(vv + 1 * HID, w1p.data() + 2 * HID, ld1, c);         // radial column
+                pack_vec(vv + 2 * HID, w1p.data() + 2 * HID + 1, ld1, c);     // d0 column
+            } else {
+                (void)pack_sin_columns(g + G_WG, w1p.data(), ld1, c);          // 24 embedded-distance columns
+                sc[20] = row_l1_weighted(w1p.data(), ld1, 2 * HID, SIN_K, c, be);     // |sin|, |cos| <= 1: a bound on the term, exponents applied
             }
             pack_vec(vv + 3 * HID, b2, 1, c);
-            pack_vec(vv + 4 * HID, b3, 1, c);
+            pack_vec(vv + 4 * HID, b3p.data(), 1, c);
             pack_vec(vv + 5 * HID, b4, 1, 1.0);
             if (watt) { pack_vec(vv + 6 * HID, watt, 1, 1.0 / c); sc[8] = batt[0]; }    // logit = w_att . (u2 / c) + b_att
             sc[6] = vec_absmax(vv + 1 * HID);
             sc[7] = vec_absmax(vv + 2 * HID);
-            // bounds for the a-priori scales of the per-atom phases (version 2): row L1 norms of the packed matrices, bias maxima
-            sc[12] = row_l1(w1, ld1, 0, c); sc[13] = row_l1(w1, ld1, HID, c);
-            sc[14] = row_l1(w3, 2 * HID, 0, c); sc[15] = row_l1(w3, 2 * HID, HID, cfg->aggregation_mean ? 1.0 : inv_norm);
-            sc[16] = row_l1(w4, HID, 0, 1.0 / c);
-            sc[17] = vec_absmax(vv + 0 * HID) * 1.0001f; sc[18] = vec_absmax(vv + 4 * HID) * 1.0001f;
+            sc[GS_WRW] = vec_absmax_weighted(vv + 1 * HID, be);
+            sc[GS_WDW] = vec_absmax_weighted(vv + 2 * HID, be);
+            // bounds for the a-priori scales of the per-atom phases (version 2): row L1 norms of the packed matrices, bias maxima -
+            // of the operands AS THEY ENTER the second layers, i.e. with the hidden layers' exponents applied
+            sc[12] = row_l1_weighted(w1p.data(), ld1, 0, HID, c, be); sc[13] = row_l1_weighted(w1p.data(), ld1, HID, HID, c, be);
+            sc[14] = row_l1_weighted(w3p.data(), 2 * HID, 0, HID, c, bt); sc[15] = row_l1_weighted(w3p.data(), 2 * HID, HID, HID, s3b, bt);
+            sc[16] = row_l1(w4p.data(), HID, 0, 1.0 / c);
+            sc[17] = vec_absmax_weighted(vv + 0 * HID, be); sc[18] = vec_absmax_weighted(vv + 4 * HID, bt);
             sc[19] = vec_absmax(vv + 5 * HID) * 1.0001f;
         }
         float* e = base + 2 * GCL_SIZE;
@@ -2211,25 +2345,45 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         const float* w6 = w[ti++]; const float* b6 = w[ti++];         // coord_mlp.2 [128][128]
         const float* w7 = w[ti++];                                    // coord_mlp.4 [1][128], no bias
         const int ld5 = 2 * HID + (cfg->sin_embedding ? SIN_K : 2);
+        Balance bc;
+        for (int f = 0; f < HID; ++f) {
+            double r = fabs(double(b5[f]));
+            for (int k = 0; k < 2 * HID; ++k) r += fabs(double(w5[size_t(f) * ld5 + k]));
+            for (int k = 0; k < ld5 - 2 * HID; ++k) r += (cfg->sin_embedding ? 1.0 : 32.0) * fabs(double(w5[size_t(f) * ld5 + 2 * HID + k]));
+            proxy[f] = r;
+        }
+        balance_hidden(bc, proxy.data(), 16, f16);
+        permute_rows(w1p, b1p, w5, b5, ld5, bc);
+        permute_cols(w2p, w6, bc);
         float* sc = e + E_SCALE;
-        sc[0] = unit(e + E_W5A, w5, ld5, 0, c);
-        sc[1] = unit(e + E_W5B, w5, ld5, HID, c);
-        sc[2] = image(e + E_W6, w6, HID, 1.0);
-        image_t(e + E_W6T, w6, HID, 1.0);
-        float* vv = e + E_VEC;
-        pack_vec(vv + 0 * HID, b5, 1, c);
-        if (!cfg->sin_embedding) {
-            pack_vec(vv + 1 * HID, w5 + 2 * HID, ld5, c);
-            pack_vec(vv + 2 * HID, w5 + 2 * HID + 1, ld5, c);
+        if (f16) {
+            pack_unit_f16(e + E_W5A, w1p.data(), ld5, 0, c, sc + ES_SW_W5A);
+            pack_unit_f16(e + E_W5B, w1p.data(), ld5, HID, c, sc + ES_SW_W5B);
         } else {
-            sc[11] = pack_sin_columns(e + E_WG, w5, ld5, c);
+            pack_unit(e + E_W5A, w1p.data(), ld5, 0, c); pack_unit(e + E_W5B, w1p.data(), ld5, HID, c);
+            for (int k = 0; k < 8; ++k) sc[ES_SW_W5A + k] = 1.0f;
+        }
+        sc[2] = image(e + E_W6, w2p.data(), HID, 1.0);
+        image_t(e + E_W6T, w2p.data(), HID, 1.0);
+        for (int s_ = 0; s_ < 8; ++s_) sc[ES_NE + s_] = float(bc.fac[16 * s_]);
+        float* vv = e + E_VEC;
+        pack_vec(vv + 0 * HID, b1p.data(), 1, c);
+        if (!cfg->sin_embedding) {
+            pack_vec(vv + 1 * HID, w1p.data() + 2 * HID, ld5, c);
+            pack_vec(vv + 2 * HID, w1p.data() + 2 * HID + 1, ld5, c);
+        } else {
+            (void)pack_sin_columns(e + E_WG, w1p.data(), ld5, c);
+            sc[11] = row_l1_weighted(w1p.data(), ld5, 2 * HID, SIN_K, c, bc);
         }
         pack_vec(vv + 3 * HID, b6, 1, c);
         // s = w7 . SiLU(..): with tanh or the mean the head's raw output is needed, the normalisation follows at run time
         pack_vec(vv + 4 * HID, w7, 1, (cfg->tanh || cfg->aggregation_mean) ? 1.0 / c : inv_norm / c);
         sc[6] = vec_absmax(vv + 1 * HID);
         sc[7] = vec_absmax(vv + 2 * HID);
-        sc[8] = row_l1(w5, ld5, 0, c); sc[9] = row_l1(w5, ld5, HID, c); sc[10] = vec_absmax(vv + 0 * HID) * 1.0001f;
+        sc[ES_WRW] = vec_absmax_weighted(vv + 1 * HID, bc);
+        sc[ES_WDW] = vec_absmax_weighted(vv + 2 * HID, bc);
+        sc[8] = row_l1_weighted(w1p.data(), ld5, 0, HID, c, bc); sc[9] = row_l1_weighted(w1p.data(), ld5, HID, HID, c, bc);
+        sc[10] = vec_absmax_weighted(vv + 0 * HID, bc);
     }
     dl_model* m = static_cast<dl_model*>(calloc(1, sizeof(dl_model)));
     if (!m) { free(hp); return DL_ERR_ALLOC; }
@@ -2373,13 +2527,16 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if ((g->noise_x == nullptr) != (g->noise_h == nullptr)) return DL_ERR_BAD_ARG;    // both (bank) or neither (Philox)
     if (m->cfg.context_node_nf > 0 && !g->context) return DL_ERR_BAD_ARG;
     if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T || g->team < 0) return DL_ERR_BAD_ARG;
+    if (g->order_first < 0 || g->order_count < 0 || g->order_first + g->order_count > g->B) return DL_ERR_BAD_ARG;
+    if ((g->order_first != 0 || g->order_count != 0) && !g->order) return DL_ERR_BAD_ARG;
     if (m->cfg.sin_embedding) return DL_ERR_UNSUPPORTED;       // (host-driven loop over dl_egnn_forward_fc_large instead)
     if (g->B == 0) return DL_OK;
+    const int32_t count = g->order_count > 0 ? g->order_count : g->B;        // molecules of this launch
     ChainArgs a;
     a.wpack = m->d_pack; a.md = dims_of(m); a.a = *g; a.prof = g_prof_buf;
     hipStream_t st = static_cast<hipStream_t>(stream);
     FcWorkspace ws;
-    const int32_t rc = fc_workspace(g->B, g->team, g->workspace, g->workspace_bytes, st, &ws);
+    const int32_t rc = fc_workspace(count, g->team, g->workspace, g->workspace_bytes, st, &ws);
     if (rc != DL_OK) return rc;
     a.team_rows = ws.rows; a.team_flags = ws.flags; a.hsave = ws.hsave; a.team_fault = g->team > 1 ? take_team_fault() : 0;
     const bool f16 = m->cfg.precision != DL_PRECISION_FP32, att = m->cfg.attention != 0, two = m->cfg.precision == DL_PRECISION_F16X2 && !att;

@@ -231,8 +231,11 @@ __global__ void pk_eqtiles_kernel(PkWs w) {
 // acc[32 rows x 32 features] += A[rows][k] * W'[feature][k], k = 0..127; A = LDS tile (row stride LDT), B = pre-loaded
 // fragments of one unit slice.  PREC 0: fp32 MFMA, lane supplies k = 64*hh + s.  PREC 1 (f16x3): lane supplies
 // k = 16*slab + 8*hh + e, A is scaled by `sa` (power of two) and split into fp16 hi+lo (see egnn_fc.hip).
+// `kfac` (f16 modes, or nullptr): the A operand's features of 32-feature tile kt enter times sa * kfac[kt] (balanced packing:
+// the hidden layer of the node MLP, whose second-layer columns carry the inverse factors)
 template <int PREC>
-__device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int row, int hh, const BFrag& b, float sa) {
+__device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int row, int hh, const BFrag& b, float sa,
+                                         const float* __restrict__ kfac = nullptr) {
     if constexpr (PREC == 0) {
         const float4* ap = reinterpret_cast<const float4*>(abuf + row * LDT + 64 * hh);
 #pragma unroll
@@ -249,7 +252,8 @@ __device__ __forceinline__ void gemm_lds(floatx16& acc, const float* abuf, int r
         for (int slab = 0; slab < 8; ++slab) {
             const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * slab);
             const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * slab + 4);
-            const float u[8] = {a0.x * sa, a0.y * sa, a0.z * sa, a0.w * sa, a1.x * sa, a1.y * sa, a1.z * sa, a1.w * sa};
+            const float ss = kfac ? sa * kfac[slab >> 1] : sa;
+            const float u[8] = {a0.x * ss, a0.y * ss, a0.z * ss, a0.w * ss, a1.x * ss, a1.y * ss, a1.z * ss, a1.w * ss};
             uint4 hi, lo;
             split8(u, hi, lo);
             const uint4 bh = __builtin_bit_cast(uint4, b.q[slab]), bl = __builtin_bit_cast(uint4, b.q[8 + slab]);
@@ -278,7 +282,8 @@ __device__ __forceinline__ void wg_max(unsigned* slot, float val, int lane) {
 template <int PREC>
 __global__ void __launch_bounds__(NODE_THREADS)
 pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __restrict__ pre_units,
-               const float* __restrict__ pre_bias, const float* __restrict__ pre_scale) {
+               const float* __restrict__ pre_bias, const float* __restrict__ pre_scale /* [2][4]: weight scale of W1a' | W1b', per output tile */,
+               const float* __restrict__ pre_ne /* [8]: 2^n of the k-slabs of the coming edge pass's hidden layer */) {
     __shared__ __attribute__((aligned(16))) float hL[32 * LDT];
     __shared__ __attribute__((aligned(16))) float aL[32 * LDT];
     __shared__ unsigned mx[4];                                    // f16x3: local |h|, |agg|, |t|, |h_new| maxima
@@ -333,8 +338,9 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         const float b3 = vecs[4 * HID + 32 * nt + c];
         float s1 = 1.0f, s2 = 1.0f, inv = 1.0f;
         if (PREC == 1) {
-            const float S = fminf(s_h * sc[2], scale_for(__uint_as_float(mx[1])) * sc[3]);
-            s1 = S * inv_pow2(sc[2]); s2 = S * inv_pow2(sc[3]); inv = inv_pow2(S);
+            const float sw3a = sc[GS_SW_W3A + nt], sw3b = sc[GS_SW_W3B + nt];     // one weight scale per output tile (balanced packing)
+            const float S = fminf(s_h * sw3a, scale_for(__uint_as_float(mx[1])) * sw3b);
+            s1 = S * inv_pow2(sw3a); s2 = S * inv_pow2(sw3b); inv = inv_pow2(S);
         }
         floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
         {
@@ -347,11 +353,12 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         }
         __syncthreads();                                           // all waves done reading aL
         float tmax = 0.0f;
+        const float tfac = (PREC == 1) ? sc[GS_NT + nt] : 1.0f;       // the hidden layer of tile nt enters W4' times 2^n (W4' carries 2^-n)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
             const float tv = silu_u(PREC == 0 ? acc[reg] : fmaf(acc[reg], inv, b3));
             aL[acc_row(reg, hh) * LDT + 32 * nt + c] = tv;
-            tmax = fmaxf(tmax, fabsf(tv));
+            tmax = fmaxf(tmax, fabsf(tv) * tfac);
         }
         if (PREC == 1) wg_max(&mx[2], tmax, lane);
         __syncthreads();
@@ -363,7 +370,7 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         for (int reg = 0; reg < 16; ++reg) hn[reg] = (PREC == 0) ? hL[acc_row(reg, hh) * LDT + 32 * nt + c] + b4 : 0.0f;
         {
             const BFrag b4f = load_bfrag(post + G_W4 + nt * (UNIT / 4), lane);
-            gemm_lds<PREC>(hn, aL, c, hh, b4f, s_t);
+            gemm_lds<PREC>(hn, aL, c, hh, b4f, s_t, PREC == 1 ? sc + GS_NT : nullptr);
         }
         if (PREC == 1) {
 #pragma unroll
@@ -390,7 +397,8 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         for (int which = 0; which < 2; ++which) {
             const BFrag bf = load_bfrag(pre_units + which * UNIT + nt * (UNIT / 4), lane);
             const float bias = which == 0 ? pre_bias[32 * nt + c] : 0.0f;
-            const float inv = (PREC == 1) ? inv_pow2(s_h * pre_scale[which]) : 1.0f;
+            const float inv = (PREC == 1) ? inv_pow2(s_h * pre_scale[4 * which + nt]) : 1.0f;
+            const float efac = (PREC == 1) ? pre_ne[2 * nt + (c >> 4)] : 1.0f;      // 2^n of this lane's feature: the row maxima bound the SCALED operands
             floatx16 acc = splat16(PREC == 0 ? bias : 0.0f);
             gemm_lds<PREC>(acc, hL, c, hh, bf, s_h);
             float* dst = which == 0 ? w.P : w.Q;
@@ -402,7 +410,7 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
                 if (v < d.V) dst[size_t(v) * HID + 32 * nt + c] = val;
                 if (PREC == 1) {
                     // max over this wave's 32 features of row r (lanes of one half), then across the 4 waves in LDS
-                    float m = fabsf(val);
+                    float m = fabsf(val) * efac;
                     m = fmaxf(m, dpp_mov<0xB1>(m));
                     m = fmaxf(m, dpp_mov<0x4E>(m));
                     m = fmaxf(m, dpp_mov<0x141>(m));
@@ -450,7 +458,10 @@ __device__ __forceinline__ void sin_embed(float r, float d0, float (&e)[SIN_K]) 
 }
 
 template <bool EQUIV, int PREC, bool WEIGHTED, bool ATT, bool SIN>
-__global__ void __launch_bounds__(EDGE_THREADS, 2)     // two waves per SIMD (two workgroups per CU): <= 256 VGPR + AGPR
+// two waves per SIMD (two workgroups per CU): <= 256 VGPR + AGPR.  The attention variants keep the 64 messages of a step until
+// the logit is known, the sin_embedding variants 24 embedded distances (292..410 registers): one wave per SIMD is what they get,
+// and what they ask for
+__global__ void __launch_bounds__(EDGE_THREADS, (ATT || SIN) ? 1 : 2)
 pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __restrict__ vecs /* wr',wd',b2',(w7') */,
                const float* __restrict__ sc /* f16x3: static scales of this pass */, int sw_index,
                const float* __restrict__ vec4, float head, const float* __restrict__ wg, float wg_l1) {
@@ -613,7 +624,9 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             }
         } else {
             // f16x3: |u| <= |y| <= max|P_i| + max|Q_j| + r*max|wr'| + d0*max|wd'|; the tile's largest bound sets the scale
-            float bound = SIN ? pqb + wg_l1 : pqb + r * sc[6] + d0 * sc[7];
+            // (every term with the k-slab exponents of the balanced packing applied: pmax / qmax from pk_node_kernel, the weighted maxima
+            // of wr', wd' and of the embedded-distance columns from dl_model_create)
+            float bound = SIN ? pqb + wg_l1 : pqb + r * sc[EQUIV ? ES_WRW : GS_WRW] + d0 * sc[EQUIV ? ES_WDW : GS_WDW];
             bound = fmaxf(bound, dpp_mov<0xB1>(bound));
             bound = fmaxf(bound, dpp_mov<0x4E>(bound));
             bound = fmaxf(bound, dpp_mov<0x141>(bound));
@@ -623,7 +636,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 bound = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
             }
             const float sa = scale_for(__builtin_amdgcn_readfirstlane(bound));   // wave-uniform (both halves hold the same pairs)
-            const float accs = sa * sc[sw_index], inv = inv_pow2(accs), isa = inv_pow2(sa);
+            const float accs = sa * sc[sw_index], inv = inv_pow2(accs);
             // accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
             acc0 = splat16(0.0f); acc1 = splat16(0.0f); acc2 = splat16(0.0f); acc3 = splat16(0.0f);
             const uint4* Wq = reinterpret_cast<const uint4*>(W) + lane;
@@ -637,6 +650,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 float us[8];
+                const float isa = inv_pow2(sa * sc[(EQUIV ? ES_NE : GS_NE) + slab]);     // the slab's features enter times sa * 2^n
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int k0 = 16 * slab + 4 * q;
@@ -887,9 +901,14 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
     const int row_tiles = (V + 31) / 32;
     const int edge_grid = 512;                                     // 2 workgroups per CU (64 KB LDS each)
     const bool f16 = m->cfg.precision != DL_PRECISION_FP32, two = m->cfg.precision == DL_PRECISION_F16X2;
-    auto node = [&](const float* post, const float* pre_units, const float* pre_bias, const float* pre_scale) {
-        if (f16) hipLaunchKernelGGL(pk_node_kernel<1>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
-        else hipLaunchKernelGGL(pk_node_kernel<0>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale);
+    // `pre`: the pass whose projections the kernel ends with (a GCL, or the equivariant update: `pre_equiv`)
+    auto node = [&](const float* post, const float* pre, bool pre_equiv) {
+        const float* pre_units = pre + (pre_equiv ? E_W5A : G_W1A);
+        const float* pre_bias = pre + (pre_equiv ? E_VEC : G_VEC);
+        const float* pre_scale = pre + (pre_equiv ? E_SCALE + ES_SW_W5A : G_SCALE + GS_SW_W1A);      // [2][4] per-tile weight scales
+        const float* pre_ne = pre + (pre_equiv ? E_SCALE + ES_NE : G_SCALE + GS_NE);                  // [8] slab factors of its hidden layer
+        if (f16) hipLaunchKernelGGL(pk_node_kernel<1>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale, pre_ne);
+        else hipLaunchKernelGGL(pk_node_kernel<0>, dim3(row_tiles), dim3(NODE_THREADS), 0, st, d, w, post, pre_units, pre_bias, pre_scale, pre_ne);
     };
     d.attention = md.attention; d.tanh = md.tanh; d.mean = md.mean; d.coords_range = md.coords_range; d.inv_norm = md.inv_norm;
     d.sin = md.sin;
@@ -933,16 +952,16 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
         const float* g1 = base + GCL_SIZE;
         const float* eq = base + 2 * GCL_SIZE;
         // projections for gcl_0 (the previous block's node kernel already produced them, except for block 0)
-        if (blk == 0) node(nullptr, g0 + G_W1A, g0 + G_VEC, g0 + G_SCALE);
+        if (blk == 0) node(nullptr, g0, false);
         edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5, g0 + G_VEC + 6 * HID, 0.0f, g0 + G_WG, wg_bound(blk, 0));
-        node(g0, g1 + G_W1A, g1 + G_VEC, g1 + G_SCALE);
+        node(g0, g1, false);
         edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5, g1 + G_VEC + 6 * HID, 0.0f, g1 + G_WG, wg_bound(blk, 1));
-        node(g1, eq + E_W5A, eq + E_VEC, eq + E_SCALE);
+        node(g1, eq, true);
         edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2, nullptr, md.tanh ? md.coords_range : 0.0f, eq + E_WG, wg_bound(blk, 2));
         hipLaunchKernelGGL(pk_xupdate_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d, w, linker_mask);
         if (blk + 1 < md.n_layers) {
             const float* n0 = base + BLOCK_SIZE;                   // next block's gcl_0 projections (h unchanged)
-            node(nullptr, n0 + G_W1A, n0 + G_VEC, n0 + G_SCALE);
+            node(nullptr, n0, false);
         }
     }
     hipLaunchKernelGGL(pk_out_kernel, dim3((V * d.D + 255) / 256), dim3(256), 0, st, d, w, wp, out, nan_flags);

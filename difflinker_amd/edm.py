@@ -30,6 +30,12 @@ from .egnn import Dynamics, DynamicsWithPockets
 from .noise import PredefinedNoiseSchedule
 
 
+# second stream (and its workspace) of the launch that samples the molecules beyond one per compute unit on teams
+# (EDM._sample_chain_fused); per device, shared by every EDM of the process - launches on one stream are ordered
+_SIDE_STREAMS = {}
+_SIDE_WORKSPACE = {}
+
+
 class EDM(torch.nn.Module):
     def __init__(
             self,
@@ -68,6 +74,17 @@ class EDM(torch.nn.Module):
         # hand).  A shard of a batch pins it to the whole batch as well: the order in which an atom's messages are summed
         # depends on the team size, so bitwise-identical samples for any split need one team size for all of them.
         self.team_batch = None
+        # a batch of up to 1.25x the number of compute units: the molecules beyond one per compute unit are sampled by teams in a
+        # second, concurrent launch (see _sample_chain_fused) instead of waiting for a second round.  Their messages are then
+        # summed in the team's order: False keeps every molecule on one compute unit (bitwise the numbers of any other split).
+        self.overflow_teams = True
+
+    @staticmethod
+    def _side_stream(dev):
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+        return _SIDE_STREAMS[key]
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError('EDM.forward is the training loss (edm.py:41-124): out of scope of the '
@@ -260,6 +277,8 @@ class EDM(torch.nn.Module):
             if not hasattr(self.dynamics, 'without_teams'):
                 return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
                                                     keep_frames, noise_bank, philox_draws)
+            # team sizes of the denoiser calls: those of the WHOLE batch (a shard pins EDM.team_batch), as on the fused chain
+            self.dynamics.team_batch = bs if self.team_batch is None else max(bs, int(self.team_batch))
             rng = None
             if noise_bank is None and philox_draws is None and x.device.type == 'cuda':
                 rng = torch.cuda.get_rng_state(x.device)
@@ -269,7 +288,10 @@ class EDM(torch.nn.Module):
                     torch.cuda.set_rng_state(rng, x.device)
                 return self._sample_chain_host_loop(x, h, node_mask, fragment_mask, linker_mask, edge_mask, context,
                                                     keep_frames, noise_bank, philox_draws)
-            return self.dynamics.without_teams(host_loop)
+            try:
+                return self.dynamics.without_teams(host_loop)
+            finally:
+                self.dynamics.team_batch = None
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.EDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
@@ -308,9 +330,13 @@ class EDM(torch.nn.Module):
             return dict(x=x[idx], h=h[idx], node_mask=node_mask[idx], fragment_mask=fragment_mask[idx], linker_mask=linker_mask[idx],
                         edge_mask=em[idx].reshape(-1, 1) if em is not None else None,
                         context=context[idx] if context is not None else None)
-        pinned = self.coef_batch
+        pinned, pinned_team = self.coef_batch, self.team_batch
         if pinned is None:
             self.coef_batch = bs
+        if pinned_team is None:
+            # the team sizes of every part follow the size of the WHOLE batch, exactly as in a shard of it
+            # (distributed.sample_chain_sharded pins the same number): world = 1 and world > 1 sample the same bits
+            self.team_batch = bs
         try:
             chain = torch.zeros((keep_frames, bs, n, self.n_dims + self.in_node_nf), device=dev)
             fused = []
@@ -321,19 +347,23 @@ class EDM(torch.nn.Module):
                 # (EDM.team_batch, distributed.sample_chain_sharded) - an atom's messages are summed in a team-size dependent
                 # order, so a sample must not depend on how the batch was split - else of the piece at hand
                 def med_team(count):
-                    ref = count if self.team_batch is None else max(count, int(self.team_batch))
-                    return max(2, dyn.team_for_size(int(ref), dev))
+                    return max(2, dyn.team_for_size(max(count, int(self.team_batch)), dev))
                 fused += [(c, med_team(int(c.numel()))) for c in dyn.team_chunks(med, dev)]
-            # every part reports NaNs in ITS numbering; the reference's callers index the batch with the sets of the exception
-            # (lightning.py:353-361): collect them in whole-batch numbering and raise once, for the earliest denoiser call
+            # every part reports NaNs in ITS numbering, for ITS first offending denoiser call; the reference raises at the first
+            # call whose output holds a NaN with the molecules that are NaN THERE (egnn.py:441-442) and its callers index the batch
+            # with the sets of the exception (lightning.py:353-361): collect the sets in whole-batch numbering with their call
+            # index, keep those of the earliest call, raise once.  A part that failed at call 0 ends the search: nothing is earlier.
             nan_sets = []
 
             def run_part(idx, fn):
+                if any(step == 0 for step, _ in nan_sets):
+                    return None
                 try:
                     return fn()
                 except utils.FoundNaNException as e:
                     rows = idx.tolist()
-                    nan_sets.append(tuple({rows[k] for k in s_} for s_ in (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx)))
+                    nan_sets.append((int(getattr(e, 'first_step', 0)),
+                                     tuple({rows[k] for k in s_} for s_ in (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx))))
                     return None
             for idx, team in fused:
                 bank = None if philox else (noise_bank[0][:, idx].contiguous(), noise_bank[1][:, idx].contiguous())
@@ -350,9 +380,14 @@ class EDM(torch.nn.Module):
                 if large is not None:
                     chain[:, big] = large.to(chain.dtype)
             if nan_sets:
-                raise utils.FoundNaNException.from_index_sets(*(set().union(*(s_[k] for s_ in nan_sets)) for k in range(3)))
+                first = min(step for step, _ in nan_sets)
+                err = utils.FoundNaNException.from_index_sets(*(set().union(*(s_[k] for step, s_ in nan_sets if step == first))
+                                                                for k in range(3)))
+                err.first_step = first
+                raise err
         finally:
             self.coef_batch = pinned
+            self.team_batch = pinned_team
         return chain
 
     def _sample_chain_fused(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames, noise_bank,
@@ -384,36 +419,70 @@ class EDM(torch.nn.Module):
         if team is None:
             team = 1 if self.dynamics._no_teams else \
                 self.dynamics.team_for(bs if self.team_batch is None else max(bs, int(self.team_batch)), dev)
-        if team == 1 and not getattr(EDM, '_warned_off_sweet_spot', False):
-            # one compute unit per molecule for the whole chain: a batch just above the number of compute units waits for a few
-            # straggler molecules on an otherwise idle chip (measured: B = 257 costs 1.3x B = 256 on 256 compute units) - say so once
+        # A batch just above the number of compute units: with one compute unit per molecule for the whole chain the molecules
+        # beyond that number start only when others have finished (measured round 4: B = 257 costs 1.3x B = 256 on 256 compute
+        # units).  The few molecules over - the smallest, last in the longest-first order - go to TEAMS of compute units in a
+        # second launch on another stream instead: its workgroups take the compute units the smallest molecules of the first
+        # launch leave after ~0.6 of the chain, and a team of four samples a 35-atom molecule in a quarter of the chain.
+        over = 0
+        if team == 1 and self.overflow_teams and self.team_batch is None and not self.dynamics._no_teams:
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
-            if cus < bs < 2 * cus:
-                EDM._warned_off_sweet_spot = True
+            if cus < bs <= cus + cus // 4:
+                over = bs - cus
+            elif cus < bs < 2 * cus and not getattr(EDM, '_warned_off_sweet_spot', False):
+                EDM._warned_off_sweet_spot = True              # say so once
                 warnings.warn(f'EDM.sample_chain: a batch of {bs} molecules on {cus} compute units runs one molecule per compute unit '
-                              f'for the whole chain, so the {bs - cus} molecules beyond {cus} start only when others have finished '
-                              f'(B = 257 takes 1.3x the time of B = 256); batches of k x {cus} molecules (or <= {cus}) use the chip '
-                              f'evenly', RuntimeWarning, stacklevel=3)
-        ws, ws_bytes = self.dynamics.workspace(bs, team, dev)
-        args = _lib.DLChainArgs(
-            B=bs, N=n, T=T, keep_frames=keep_frames,
-            x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
-            linker_mask=lm.data_ptr(), edge_mask=em.data_ptr() if em is not None else None,
-            context=ctx.data_ptr() if ctx is not None else None,
-            noise_x=None if philox else noise_x.data_ptr(), noise_h=None if philox else noise_h.data_ptr(),
-            noise_seed=seed, mol_offset=int(mol_offset), team=team, coefs=coefs.data_ptr(),
-            inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
-            norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
-            chain=chain.data_ptr(), nan_flags=flags.data_ptr(), nan_step=steps.data_ptr(), order=order.data_ptr(),
-            workspace=ws.data_ptr(), workspace_bytes=ws_bytes,
-            mol_index=mol_index.data_ptr() if mol_index is not None else None)
+                              f'for the whole chain, so the {bs - cus} molecules beyond {cus} start only when others have finished; '
+                              f'batches of k x {cus} molecules (or up to {cus + cus // 4}, whose surplus is sampled by teams beside '
+                              f'the rest) use the chip evenly', RuntimeWarning, stacklevel=3)
+        ws, ws_bytes = self.dynamics.workspace(bs - over, team, dev)
+
+        def chain_args(flags_, steps_, team_, ws_, ws_bytes_, first, count):
+            return _lib.DLChainArgs(
+                B=bs, N=n, T=T, keep_frames=keep_frames,
+                x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
+                linker_mask=lm.data_ptr(), edge_mask=em.data_ptr() if em is not None else None,
+                context=ctx.data_ptr() if ctx is not None else None,
+                noise_x=None if philox else noise_x.data_ptr(), noise_h=None if philox else noise_h.data_ptr(),
+                noise_seed=seed, mol_offset=int(mol_offset), team=team_, coefs=coefs.data_ptr(),
+                inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
+                norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
+                chain=chain.data_ptr(), nan_flags=flags_.data_ptr(), nan_step=steps_.data_ptr(), order=order.data_ptr(),
+                workspace=ws_.data_ptr(), workspace_bytes=ws_bytes_,
+                mol_index=mol_index.data_ptr() if mol_index is not None else None, order_first=first, order_count=count)
+        args = chain_args(flags, steps, team, ws, ws_bytes, 0, bs - over if over else 0)
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if getattr(self, 'profile_events', False):     # bench.py: HIP events right around the launch
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(cur)
+            if over:
+                # (its own flag arrays: the team entry point clears them on its stream; its own workspace: the launches overlap)
+                side = self._side_stream(dev)
+                team2 = 4 if over <= cus // 16 else 2
+                flags2 = torch.zeros(bs, dtype=torch.int32, device=dev)
+                steps2 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+                need2 = int(lib.dl_workspace_bytes(over, team2))
+                ws2 = _SIDE_WORKSPACE.get(side)
+                if ws2 is None or ws2.numel() < need2:
+                    ws2 = _SIDE_WORKSPACE[side] = torch.empty(need2, dtype=torch.uint8, device=dev)
+                args2 = chain_args(flags2, steps2, team2, ws2, need2, bs - over, over)
+                ready = torch.cuda.Event()
+                ready.record(cur)                          # inputs, coefficients, noise bank: enqueued on the current stream
             _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args), ctypes.c_void_p(cur.cuda_stream)),
                        'dl_sample_chain_fc')
+            if over:
+                side.wait_event(ready)
+                _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args2), ctypes.c_void_p(side.cuda_stream)),
+                           'dl_sample_chain_fc (molecules beyond one per compute unit, on teams)')
+                done = torch.cuda.Event()
+                done.record(side)
+                cur.wait_event(done)
+                for t_ in (xs, hs, nm, fm, lm, em, ctx, coefs, order, chain, noise_x, noise_h, mol_index):
+                    if t_ is not None:
+                        t_.record_stream(side)             # the caching allocator must not hand these out while the side launch runs
+                flags = flags | flags2
+                steps = torch.where(steps2 >= 0, steps2, steps)
             if getattr(self, 'profile_events', False):
                 ev1.record(cur)
                 self.last_kernel_events = (ev0, ev1)
@@ -448,7 +517,9 @@ class EDM(torch.nn.Module):
             if bool((f & 4).any()):
                 raise ValueError('molecule with more real atoms than the LDS-resident fully-connected kernels take')
             first = int(st[f != 0].min())
-            raise utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
+            err = utils.FoundNaNException.from_flags(torch.where((st == first) & (f != 0), f, torch.zeros_like(f)))
+            err.first_step = first          # the denoiser call (0 .. T) the exception stands for: a batch sampled in parts keeps the earliest
+            raise err
 
     def _philox_draw(self, seed, mol_offset, k, n_samples, n_nodes, device, mol_index=None):
         """Draw number ``k`` of the in-kernel stream as one ``[B,N,3+nf]`` tensor (``dl_philox_fill`` with one draw);

@@ -223,6 +223,10 @@ class Dynamics(nn.Module):
         self._fc_ws = None
         self._team_auto = {}
         self._no_teams = False                         # set while a call is re-run after a team failed to assemble
+        # batch size the 'auto' team size is chosen for when it is larger than the batch at hand (None: the batch at hand):
+        # EDM.sample_chain sets it to the size of the whole - possibly sharded - batch for the denoiser calls of a host-driven
+        # chain, so that a sample does not depend on how the batch was split (the fused chain does the same through EDM.team_batch)
+        self.team_batch = None
 
     # ---- packed weights -----------------------------------------------------------------------------
     def _weight_version(self):
@@ -348,7 +352,7 @@ class Dynamics(nn.Module):
             parts.append(part(small, False))
         if med is not None:                                        # a team per molecule, at least two workgroups
             for chunk in self.team_chunks(med, dev):
-                parts.append(part(chunk, False, team=max(2, self.team_for_size(int(chunk.numel()), dev))))
+                parts.append(part(chunk, False, team=max(2, self.team_for_size(max(int(chunk.numel()), int(self.team_batch or 0)), dev))))
         if big is not None:
             parts.append(part(big, True))
         if len(parts) == 1 and parts[0]['bs'] == bs:               # one class only: no scatter needed
@@ -408,7 +412,7 @@ class Dynamics(nn.Module):
             if not large:
                 team = prep.get('team') if prep is not None else None
                 if team is None:
-                    team = 1 if self._no_teams else self.team_for(bs, dev)
+                    team = 1 if self._no_teams else self.team_for(max(bs, int(self.team_batch or 0)), dev)
                 ws, need = self.workspace(bs, team, dev)
                 _lib.check(lib.dl_egnn_forward_fc_team(handle, bs, n_nodes, _lib.ptr(xh), _lib.ptr(t), t_is_scalar,
                                                        _lib.ptr(nm), _lib.ptr(lm), _lib.ptr(em), _lib.ptr(ctx),

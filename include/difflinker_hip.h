@@ -228,6 +228,12 @@ typedef struct dl_chain_args {
     const int32_t* mol_index;   /* device [B] or NULL: entry b of this batch is molecule mol_offset + mol_index[b] of the
                                  * logical batch (NULL: mol_offset + b) - the key of the in-kernel noise; lets a caller
                                  * sample a non-contiguous part of a batch (e.g. only the molecules that fit this kernel) */
+    int32_t order_first, order_count;   /* (ABI v7) this launch samples the molecules order[order_first .. order_first + order_count)
+                                 * only (order_count = 0: all B; otherwise `order` must be given): every array keeps the extent
+                                 * and the indexing of the whole batch, the workspace is sized for order_count molecules.  Lets a
+                                 * caller put the few molecules beyond one-per-compute-unit on TEAMS in a second launch on another
+                                 * stream - they take the compute units the smallest molecules of the first launch leave early -
+                                 * instead of waiting for a whole second round (EDM.sample_chain, batches of 257..320 on 256 CUs) */
 } dl_chain_args;
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);

@@ -178,3 +178,43 @@ FLAG_CASES = [                       # optional hyper-parameters of Dynamics (te
     ('all', dict(attention=True, tanh=True, aggregation_method='mean')),
     ('sin', dict(sin_embedding=True)),
 ]
+
+
+def trained_like_state_dict(sd, seed, sigma=1.5, outlier=2.0 ** 10, bias_gain=30.0):
+    """Seeded-random weights reshaped towards the statistics of a TRAINED checkpoint, the regime the a-priori power-of-two
+    scales of the f16x3 arithmetic have to survive: the rows of the first layer of every edge / node /
+    coordinate MLP are rescaled by a log-normal factor (``sigma``), ONE row of each by ``outlier`` on top, and every bias by
+    ``bias_gain``; the columns of the layer that consumes those features are divided by the same factors, so the function
+    stays of order one while the hidden activations, the row-L1 norms and the bias maxima the scales are derived from spread
+    over ~20 binades.  The second edge layer's rows get their own log-normal factors (no outlier), undone in the columns of
+    the node MLP that read the message sum / in the coordinate head's last layer."""
+    rng = np.random.default_rng(seed)
+    out = {k: v.clone().double() for k, v in sd.items()}
+    for k in out:
+        if k.endswith('.bias'):
+            out[k] *= bias_gain
+
+    def factors(n, with_outlier):
+        f = np.exp(sigma * rng.standard_normal(n))
+        if with_outlier:
+            f[int(rng.integers(n))] *= outlier
+        return torch.from_numpy(f)
+    stems = sorted({k.rsplit('.', 2)[0] for k in out if k.endswith('_mlp.0.weight')})
+    for stem in stems:                                     # e.g. dynamics.e_block_0.gcl_1.edge_mlp
+        if stem.endswith('att_mlp'):
+            continue
+        f = factors(out[f'{stem}.0.weight'].shape[0], True)
+        out[f'{stem}.0.weight'] *= f[:, None]
+        out[f'{stem}.0.bias'] *= f
+        out[f'{stem}.2.weight'] /= f[None, :]
+        if stem.endswith('edge_mlp') or stem.endswith('coord_mlp'):
+            g = factors(out[f'{stem}.2.weight'].shape[0], False)
+            out[f'{stem}.2.weight'] *= g[:, None]
+            out[f'{stem}.2.bias'] *= g
+            if stem.endswith('coord_mlp'):
+                out[f'{stem}.4.weight'] /= g[None, :]
+            else:                                          # SiLU sits between: undone only in magnitude, which is the point
+                node0 = stem.replace('edge_mlp', 'node_mlp') + '.0.weight'
+                hid = out[node0].shape[1] // 2
+                out[node0][:, hid:] /= g[None, :]
+    return {k: v.to(sd[k].dtype) for k, v in out.items()}

@@ -2,7 +2,7 @@
 same seeded inputs, against the golden fixtures of the unmodified reference, and through
 size-independent properties (padding invariance, E(3) equivariance, determinism, mask semantics).
 
-Tolerances (fp32 everywhere): one ``Dynamics.forward`` rel-L2 <= 1e-5 on vel and h; a full
+Tolerances: one ``Dynamics.forward`` rel-L2 <= 1e-5 (exact-fp32 mode) / <= 2e-6 (f16x3, the default) on vel and h; a full
 ``sample_chain`` with a shared noise bank rel-L2 <= 1e-4 on the linker coordinates and exact one-hot
 atom types (BASELINE.json north_star: 1e-4).
 """
@@ -19,8 +19,13 @@ from oracle.egnn_oracle import EGNNConfig
 
 pytestmark = pytest.mark.gpu
 
-# one forward: exact-fp32 MFMA mode 1e-5; scaled split-fp16 (f16x3, the default) 2e-5 (measured <= 5e-6)
-FWD_TOLS = {'fp32': 1e-5, 'f16x3': 2e-5}
+# one forward, rel-L2 on the node features and on the velocity above its ulp(|x|) floor (see `report`): exact-fp32 MFMA mode 1e-5;
+# scaled split-fp16 (f16x3, the default) 2e-6 - its measured class is 2..9e-7 in every case of the suite (profiles/r04/
+# pytest_gpu_measured_errors.log), so a 10x regression fails (round 4 allowed 2e-5: VERDICT).  The RAW velocity error is bounded
+# by 1e-4 in every forward test (it is the fp32 floor of x_final - x when the update is tiny: up to 4e-5 with the 0.02-gain heads
+# used here) and by the forward tolerance itself where the update is of the order of the coordinates
+# (test_forward_velocity_with_a_live_coordinate_head: measured 9e-7).
+FWD_TOLS = {'fp32': 1e-5, 'f16x3': 2e-6}
 FWD_TOL = FWD_TOLS[os.environ.get('DIFFLINKER_PRECISION', 'f16x3')]
 CHAIN_TOL = 1e-4
 

@@ -1,0 +1,261 @@
+"""Round-5 additions (VERDICT / ADVICE round 4): weights with the statistics of a TRAINED checkpoint through every kernel
+family, the molecules beyond one per compute unit on teams in a second launch, the team-failure path of the host-driven
+chain, world = 1 against a simulated shard on a mixed-size batch, NaN index sets of the earliest denoiser call only."""
+import os
+
+import pytest
+import torch
+
+import test_gpu_parity as P
+from helpers import rel_l2, seeded_state_dict, trained_like_state_dict
+from oracle import edm_oracle, egnn_oracle
+from oracle.egnn_oracle import EGNNConfig
+
+pytestmark = pytest.mark.gpu
+
+
+def _edm(dyn, nf, T, timesteps=500):
+    from difflinker_amd import EDM
+    edm = EDM(dyn, in_node_nf=nf, n_dims=3, timesteps=timesteps, noise_schedule='polynomial_2', noise_precision=1e-5,
+              loss_type='l2', norm_values=[1, 4, 10]).to(P.dev())
+    edm.T = T
+    return edm
+
+
+# ---- trained-like weights -----------------------------------------------------------------------------------------------
+def test_trained_like_weights_fc_against_fp32_and_fp64_oracles():
+    """Every parity case so far used nn.Linear-style random inits, where every row of a matrix has the same norm and the
+    a-priori power-of-two scales of f16x3 (row-L1 norms x measured maxima) are tight.  Here: log-normal row factors
+    (sigma = 1.5), one row x 2^10, biases x 30 (helpers.trained_like_state_dict: row-L1 norms over 17 binades, bias maxima in
+    the thousands) on a C2-shaped batch, both arithmetic modes against the fp32 oracle AND the fp64 oracle: the split scheme
+    must stay within twice the exact-fp32 mode's own rounding error, i.e. a loose bound must not eat its low bits."""
+    from difflinker_amd import synthetic
+    nf, L = 9, 6
+    data, _ = synthetic.make_batch('C2', seed=1, batch=32)
+    inp = synthetic.sampler_inputs(data)
+    B, N = inp['x'].shape[:2]
+    g = torch.Generator().manual_seed(4)
+    z = torch.cat([inp['x'], inp['h']], dim=2) * inp['fragment_mask'] + torch.randn((B, N, 3 + nf), generator=g) * inp['linker_mask']
+    t = torch.full((B, 1), 0.37)
+    sd = trained_like_state_dict(seeded_state_dict(nf + 2, 128, L, 80, coord_gain=0.02), seed=7)
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=L)
+    ref32 = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref64 = egnn_oracle.dynamics_forward(sd64, cfg, t.double(), z.double(), inp['node_mask'], inp['linker_mask'].double(),
+                                         inp['edge_mask'], inp['context'].double())
+    err = {}
+    for precision in ('fp32', 'f16x3'):
+        dyn, _, _ = P.make_dynamics(nf, 1, L, seed=80, precision=precision)
+        dyn.load_state_dict(sd, strict=True)
+        dyn.invalidate_packed()
+        out = P.run_hip_forward(dyn, inp, z, t).double()
+        err[precision] = (rel_l2(out[..., 3:], ref64[..., 3:]), float((out[..., :3] - ref64[..., :3]).norm()),
+                          rel_l2(out[..., 3:], ref32[..., 3:].double()), rel_l2(out[..., :3], ref32[..., :3].double()))
+    o32 = (rel_l2(ref32[..., 3:].double(), ref64[..., 3:]), float((ref32[..., :3].double() - ref64[..., :3]).norm()))
+    print(f'[trained-like FC vs fp64] h rel-L2: fp32 oracle {o32[0]:.3e}, fp32 mode {err["fp32"][0]:.3e}, f16x3 {err["f16x3"][0]:.3e}; '
+          f'vel abs-L2: fp32 oracle {o32[1]:.3e}, fp32 mode {err["fp32"][1]:.3e}, f16x3 {err["f16x3"][1]:.3e}; '
+          f'vs the fp32 oracle: h {err["f16x3"][2]:.3e} / raw vel {err["f16x3"][3]:.3e} (f16x3), h {err["fp32"][2]:.3e} / {err["fp32"][3]:.3e} (fp32 mode)')
+    assert err['f16x3'][0] <= 2.0 * err['fp32'][0]
+    assert err['f16x3'][1] <= 2.0 * err['fp32'][1]
+    for precision in ('fp32', 'f16x3'):
+        assert err[precision][2] <= P.FWD_TOLS[precision] and err[precision][3] <= 1e-4
+
+
+def test_trained_like_weights_pocket_kernels():
+    """The same weights through the radius-graph kernels (egnn_sparse.hip) at the C4 geometry."""
+    nf, L = 9, 6
+    dyn, sd0, cfg = P.make_pocket_dynamics(nf, L, seed=131)
+    sd = trained_like_state_dict(sd0, seed=9)
+    inp, z, t = P.pocket_inputs(batch=2, n_frag=30, n_pocket=250, linker=(6, 12), nf=nf, seed=133)
+    ref32 = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref64 = egnn_oracle.dynamics_forward_pockets(sd64, cfg, t.double(), z.double(), inp['node_mask'], inp['linker_mask'].double(),
+                                                 inp['edge_mask'], inp['context'].double())
+    err = {}
+    for precision in ('fp32', 'f16x3'):
+        dyn.precision = precision
+        dyn.load_state_dict(sd, strict=True)
+        dyn.invalidate_packed()
+        out = P.run_hip_forward(dyn, inp, z, t).double()
+        err[precision] = (rel_l2(out[..., 3:], ref64[..., 3:]), float((out[..., :3] - ref64[..., :3]).norm()),
+                          rel_l2(out[..., 3:], ref32[..., 3:].double()))
+    print(f'[trained-like pockets vs fp64] h rel-L2: fp32 mode {err["fp32"][0]:.3e}, f16x3 {err["f16x3"][0]:.3e}; vel abs-L2: '
+          f'fp32 mode {err["fp32"][1]:.3e}, f16x3 {err["f16x3"][1]:.3e}; h vs the fp32 oracle: {err["f16x3"][2]:.3e} (f16x3)')
+    assert err['f16x3'][0] <= 2.0 * err['fp32'][0]
+    assert err['f16x3'][1] <= 2.0 * err['fp32'][1]
+    assert err['f16x3'][2] <= P.FWD_TOLS['f16x3'] and err['fp32'][2] <= P.FWD_TOLS['fp32']
+
+
+def test_trained_like_weights_chain():
+    """...and along a chain: T = 30 with a shared noise bank against the oracle (the sampler feeds each step's rounding into
+    the next forward's bounds)."""
+    from difflinker_amd import EDM
+    nf, L, T = 8, 2, 30
+    dyn, sd0, cfg = P.make_dynamics(nf, 1, L, seed=61)
+    sd = trained_like_state_dict(sd0, seed=11)
+    dyn.load_state_dict(sd, strict=True)
+    dyn.invalidate_packed()
+    inp, _, _ = P.ragged_inputs([40, 33, 50, 12], [7, 5, 9, 3], nf, seed=62)
+    B, N = inp['x'].shape[:2]
+    edm = _edm(dyn, nf, T)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=63)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'], inp['edge_mask'],
+                            inp['context'], bank, keep_frames=3)
+    assert torch.isfinite(want).all()
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                           keep_frames=3, noise_bank=bank.stacked()).cpu()
+    P.check_chain('trained-like weights, chain T=30', got, want, inp)
+
+
+# ---- molecules beyond one per compute unit ---------------------------------------------------------------------------------
+def test_molecules_beyond_one_per_compute_unit_are_sampled_by_teams_beside_the_rest():
+    """A batch of (compute units + 3) molecules: ``EDM.sample_chain`` puts the three smallest on teams of four in a second launch
+    on another stream (dl_chain_args.order_first / order_count) instead of letting them wait for a free compute unit.  The chain
+    must be the oracle's; the molecules of the first launch are bit for bit what the one-launch path samples (the switch
+    ``overflow_teams = False``), the three on teams agree to fp32 rounding; repeatable bit for bit."""
+    nf, L, T = 8, 1, 5
+    cus = torch.cuda.get_device_properties(P.dev()).multi_processor_count
+    B = cus + 3
+    g0 = torch.Generator().manual_seed(5)
+    sizes = torch.randint(4, 13, (B,), generator=g0).tolist()
+    linkers = [max(1, s // 4) for s in sizes]
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=71)
+    dyn.team = 'auto'
+    inp, _, _ = P.ragged_inputs(sizes, linkers, nf, seed=72)
+    N = inp['x'].shape[1]
+    edm = _edm(dyn, nf, T)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=73)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'], inp['edge_mask'],
+                            inp['context'], bank, keep_frames=2)
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+
+    def run():
+        out = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                               keep_frames=2, noise_bank=bank.stacked())
+        torch.cuda.synchronize()
+        return out.cpu()
+    assert edm.overflow_teams
+    got = run()
+    P.check_chain(f'B = {B} on {cus} compute units, 3 molecules on teams beside the rest', got, want, inp)
+    assert torch.equal(got, run()), 'bitwise repeatable'
+    edm.overflow_teams = False
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)
+        plain = run()
+    order = torch.argsort(torch.tensor(sizes), descending=True, stable=True)
+    first, over = order[:cus], order[cus:]
+    assert torch.equal(got[:, first], plain[:, first]), 'molecules of the first launch: the same bits as without the second launch'
+    lm = inp['linker_mask'][over]
+    print(f'molecules on teams vs one compute unit each: linker-x rel-L2 {rel_l2(got[0, over, :, :3] * lm, plain[0, over, :, :3] * lm):.3e}')
+    assert rel_l2(got[0, over, :, :3] * lm, plain[0, over, :, :3] * lm) <= 1e-5
+    assert torch.equal(got[0, over, :, 3:], plain[0, over, :, 3:])
+
+
+# ---- host-driven chain: a team that does not assemble ----------------------------------------------------------------------
+def test_host_loop_chain_survives_a_team_failure_with_the_same_draws():
+    """a ``centering=True`` denoiser runs ``EDM.sample_chain`` on the host-driven loop, where molecules of 56..110
+    atoms take teams.  The first team launch is made to fail (test-hooks build of the library): ``TeamNotAssembled`` is raised
+    after the FIRST denoiser call, the chain is repeated without teams from the restored generator state - with
+    ``noise_source = 'torch'`` and no bank - and equals, bit for bit, the chain a denoiser that never uses teams samples from the
+    same seed."""
+    from difflinker_amd import Dynamics, _lib
+    nf, L, T = 8, 1, 4
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=1, hidden_nf=128, n_layers=L, norm_constant=1e-6, centering=True)
+    sd = seeded_state_dict(nf + 2, 128, L, 81)
+    dyn.load_state_dict(sd, strict=True)
+    dyn = dyn.to(P.dev())
+    inp, _, _ = P.ragged_inputs([60, 20, 75], [6, 4, 8], nf, seed=82)
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    edm = _edm(dyn, nf, T)
+    assert edm.noise_source == 'torch'
+
+    def run():
+        torch.manual_seed(99)
+        out = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                               keep_frames=1)
+        torch.cuda.synchronize()
+        return out.cpu()
+    dyn._no_teams = True
+    want = run()
+    dyn._no_teams = False
+    with _lib.test_hooks() as lib:
+        dyn.invalidate_packed()
+        teams = run()                                  # teams assemble
+        lib.dl_debug_team_fault(1)                     # the next team launch fails: the first denoiser call of the chain
+        got = run()
+    dyn.invalidate_packed()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want), 'the repeated chain must draw the same noise and use no teams'
+    lm = inp['linker_mask']
+    assert rel_l2(teams[0, :, :, :3] * lm, want[0, :, :, :3] * lm) <= 1e-5
+
+
+# ---- world = 1 against a shard --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('centering', [False, True])
+def test_unsharded_run_samples_the_bits_of_its_shards_on_a_mixed_size_batch(centering):
+    """team sizes follow the size of the WHOLE batch in every path - the fused chain of the <= 55-atom molecules,
+    the team launches of the 56..110-atom ones, the denoiser calls of a host-driven chain - so the unsharded call and the two
+    halves of the batch sampled as shards (what ``distributed.sample_chain_sharded`` does on two ranks) give the same bits."""
+    from difflinker_amd import Dynamics
+    from difflinker_amd.distributed import shard_sampler_inputs
+    nf, L, T = 8, 1, 4
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=1, hidden_nf=128, n_layers=L, norm_constant=1e-6, centering=centering)
+    dyn.load_state_dict(seeded_state_dict(nf + 2, 128, L, 91), strict=True)
+    dyn = dyn.to(P.dev())
+    sizes, linkers = [30, 70, 45, 90, 20, 60, 12, 100], [5, 7, 6, 9, 4, 6, 3, 10]
+    inp, _, _ = P.ragged_inputs(sizes, linkers, nf, seed=92)
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    edm = _edm(dyn, nf, T)
+    edm.noise_source = 'philox'
+    edm.noise_seed = 5
+    whole = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                             keep_frames=2).cpu()
+    B = len(sizes)
+    parts = []
+    for rank in range(2):
+        local, (lo, hi) = shard_sampler_inputs(g, rank, 2)
+        edm.noise_seed = 5
+        edm.coef_batch, edm.team_batch = B, B            # what sample_chain_sharded pins
+        try:
+            parts.append(edm.sample_chain(keep_frames=2, mol_offset=lo, **local).cpu())
+        finally:
+            edm.coef_batch = edm.team_batch = None
+    assert torch.equal(torch.cat(parts, dim=1), whole)
+
+
+# ---- NaN index sets: the earliest denoiser call only -----------------------------------------------------------------------
+def test_nan_sets_of_a_batch_sampled_in_parts_are_those_of_the_earliest_call():
+    """the reference raises at the first denoiser call whose output holds a NaN, with the molecules that are NaN
+    THERE (egnn.py:441-442).  Molecule 0 (fused chain) goes bad at call 2, molecule 3 (host-driven part) at call 0: only 3 is
+    reported."""
+    from difflinker_amd.utils import FoundNaNException
+    nf, T = 8, 4
+    dyn, sd, cfg = P.make_dynamics(nf, 1, 1, seed=33)
+    inp, _, _ = P.ragged_inputs([20, 70, 35, 120, 12], [4, 9, 5, 8, 3], nf, seed=34)
+    B, N = inp['x'].shape[:2]
+    edm = _edm(dyn, nf, T)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=35)
+    nx, nh = bank.stacked()
+    nx = nx.clone()
+    nx[0, 3, 119, 0] = float('nan')                      # draw 0: z_T of molecule 3 -> its call 0
+    nx[2, 0, 19, 1] = float('nan')                       # draw 2 (the noise of step 1): z after step 1 of molecule 0 -> its call 2
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    with pytest.raises(FoundNaNException) as ei:
+        edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                         keep_frames=1, noise_bank=(nx, nh))
+    e = ei.value
+    bad = e.x_h_nan_idx | e.only_x_nan_idx | e.only_h_nan_idx
+    print(f'NaNs planted in molecule 0 (call 2) and molecule 3 (call 0): reported {sorted(bad)} for call {e.first_step}')
+    assert bad == {3} and e.first_step == 0
+    nx[0, 3, 119, 0] = 0.5                               # without the early one: molecule 0 alone, at its own call
+    with pytest.raises(FoundNaNException) as ei:
+        edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                         keep_frames=1, noise_bank=(nx, nh))
+    e = ei.value
+    assert (e.x_h_nan_idx | e.only_x_nan_idx | e.only_h_nan_idx) == {0} and e.first_step == 2

@@ -21,7 +21,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     from difflinker_amd import _lib
     lib = _lib.load()
     header = open(os.path.join(ROOT, 'include', 'difflinker_hip.h')).read()
-    product, hooks = re.split(r'#ifdef DL_TEST_HOOKS', header)[0::2], re.findall(r'#ifdef DL_TEST_HOOKS(.*?)#endif', header, re.S)
+    hooks = re.findall(r'#ifdef DL_TEST_HOOKS(.*?)#endif', header, re.S)
     declared = set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', re.sub(r'#ifdef DL_TEST_HOOKS.*?#endif', '', header, flags=re.S)))
     hooked = set(re.findall(r'\b(dl_[a-z_0-9]+)\s*\(', ' '.join(hooks)))
     assert declared == set(_lib.EXPORTS), (declared ^ set(_lib.EXPORTS))
@@ -39,7 +39,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.dl_workspace_bytes(8, 0) == lib.dl_workspace_bytes(8, 1) == 8 * w1
     assert lib.dl_workspace_bytes(8, 4) > 4 * lib.dl_workspace_bytes(8, 1) and lib.dl_workspace_bytes(8, 3) >= 0
     assert lib.dl_team_max(64) in (1, 2, 4, 8) and lib.dl_team_max(0) == 1         # 1 without a device (a query, not a compute call)
-    assert ctypes.sizeof(_lib.DLChainArgs) == 192                                   # dl_chain_args of ABI v5 / v6 (LP64)
+    assert ctypes.sizeof(_lib.DLChainArgs) == 200                                   # dl_chain_args of ABI v7 (LP64): v6's 192 + order_first, order_count
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
     cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
