@@ -362,15 +362,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == a.gpus or (a.gpus == 1 and world == 1), f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    if world > 1 and a.backend == 'gloo':                  # several ranks on one GPU (functional check): the rendezvous needs no device,
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')  # so it - and one collective - runs before the device check (CPU test of --gpus 8)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        seen = torch.ones(1)
+        dist.all_reduce(seen)
+        print(f'rank {rank}/{world} joined ({int(seen)} ranks in the group)', file=sys.stderr, flush=True)
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
     device = torch.device('cuda', local_rank if a.backend == 'nccl' else local_rank % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 and a.backend == 'nccl':
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if a.backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
-        else:                                              # several ranks on one GPU (functional check)
-            dist.init_process_group('gloo', rank=rank, world_size=world)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -497,6 +500,11 @@ def main():
                          # kept for continuity with rounds 1-2, whose lines carried the executed figures under this key
                          'executed': {'achieved': executed, 'frac': executed / peak, 'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1)}},
             'per_rank': per_rank,
+            'per_rank_note': None if per_rank is None else
+                'all_gather_ms is measured on each rank from the moment ITS chain is enqueued-complete to the end of the collective: it '
+                'contains the wait for the slowest rank (a rank whose kernel ends early shows the difference of the kernel times here - '
+                'round 4: 99 ms on the rank that finished first against 5.5 ms on the last, two gloo ranks sharing one GPU, whose kernels '
+                'run one after the other) plus the transfer itself (<= 1 MB per rank)',
             'hbm_layer': {'achieved': layer_bytes / t_layer / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                           'frac': layer_bytes / t_layer / 1e9 / HBM_PEAK_GBS,
                           'note': 'EGNN-layer algorithmic bytes (SURVEY 8d A_layer) / time per block; the molecule is '

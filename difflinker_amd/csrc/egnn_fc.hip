@@ -896,7 +896,9 @@ constexpr int SCE_L1_W5A = 8, SCE_L1_W5B = 9, SCE_B5 = 10;
 // reload afterwards waits for ALL vector-memory traffic in flight (s_waitcnt vmcnt(0): the counter is in order) - measured
 // round 3: ten such reloads in the 2 us reduction alone.
 constexpr int CX_N = 16, CX_EM = 17, CX_HS = 19, CX_WP = 21, CX_PASS = 23, CX_PAR = 24, CX_FLAGS = 25, CX_NORMC = 26,
-              CX_CRANGE = 27, CX_INVNORM = 28, CX_NPASS = 29, CX_NF = 30, CX_FIN = 31, CX_TFEAT = 32, CX_MOL = 33, CX_CTXP = 34;
+              CX_CRANGE = 27, CX_INVNORM = 28, CX_NPASS = 29, CX_NF = 30, CX_FIN = 31, CX_TFEAT = 32, CX_MOL = 33, CX_CTXP = 34,
+              CX_SUB = 36, CX_CT = 37;      // inv_sublayers (GCLs per block), condition_time
+static_assert(CX_CT < MISC_WORDS, "context block");
 __device__ __forceinline__ int ctx_i(const Lds& v, int k) {
     typedef volatile __attribute__((address_space(3))) int* lds_vint_t;       // a plain ds_read_b32 (a volatile GENERIC access is a flat sc0 sc1 load)
     return __builtin_amdgcn_readfirstlane(*(lds_vint_t)(v.misc + k));
@@ -919,19 +921,22 @@ struct PassCtx {
     const int8_t* em;
     NextPass nx;
 };
-__device__ __forceinline__ const float* pass_weights(const float* wp, int pass) {
-    return wp + OFF_BLOCKS + size_t(pass / 3) * BLOCK_SIZE + (pass % 3) * GCL_SIZE;     // GCL, GCL, equivariant update
+// a block = `sub` GCLs (inv_sublayers: 2 in every released configuration), then the equivariant update
+__device__ __forceinline__ const float* pass_weights(const float* wp, int pass, int sub) {
+    const int blk = pass / (sub + 1), k = pass - blk * (sub + 1);
+    return wp + OFF_BLOCKS + size_t(blk) * block_size(sub) + k * GCL_SIZE;
 }
 __device__ __forceinline__ PassCtx pass_ctx(const Lds& v) {
     PassCtx c;
     c.nb = ctx_i(v, 0); c.N = ctx_i(v, CX_N); c.pass = ctx_i(v, CX_PASS); c.par = ctx_i(v, CX_PAR); c.flags = ctx_i(v, CX_FLAGS);
     const float* wp = ctx_p<const float>(v, CX_WP);
-    c.g = pass_weights(wp, c.pass);
+    const int sub = ctx_i(v, CX_SUB);
+    c.g = pass_weights(wp, c.pass, sub);
     c.hs = ctx_p<float>(v, CX_HS);
     c.em = ctx_p<const int8_t>(v, CX_EM);
     const int nxt = c.pass + 1;
-    c.nx.base = nxt < ctx_i(v, CX_NPASS) ? pass_weights(wp, nxt) : nullptr;
-    c.nx.equiv = (nxt % 3) == 2;
+    c.nx.base = nxt < ctx_i(v, CX_NPASS) ? pass_weights(wp, nxt, sub) : nullptr;
+    c.nx.equiv = (nxt % (sub + 1)) == sub;
     return c;
 }
 // the kernel's own arguments through the scalar cache, re-read where used (see above)
@@ -1460,7 +1465,8 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         }
         const float be = wp[OFF_EMB_B + f];
         const float* ctxp = ctx_p<const float>(v, CX_CTXP);                 // this molecule's context rows [N][nctx]
-        const int nctx = fin - nf - 1;
+        const int ct = ctx_i(v, CX_CT);                                     // condition_time: [h_feat, t, context] or [h_feat, context] (egnn.py:396-407)
+        const int nctx = fin - nf - ct;
         float hmax = 0.0f;
         for (int l = tid >> 7; l < nown; l += THREADS / HID) {
             const int pos = v.idx[rank + l * S];
@@ -1469,8 +1475,8 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
             for (int k = 0; k < FINP; ++k) {
                 float hin = 0.0f;
                 if (k < nf) hin = v.z[l * DMAX + 3 + k];
-                else if (k == nf) hin = tfeat;
-                else if (k < fin) hin = ctxp[pos * nctx + (k - nf - 1)];
+                else if (k < nf + ct) hin = tfeat;
+                else if (k < fin) hin = ctxp[pos * nctx + (k - nf - ct)];
                 acc = fmaf(wrow[k], hin, acc);
             }
             v.B[l * LDH + f] = acc;
@@ -1496,10 +1502,11 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         load_pre2(pw, first, w, lane, nown);
         open_pass<PREC, TEAM>(v, nb, nown, first, hs, pf, pw, 0, 0);
     }
+    const int sub = ctx_i(v, CX_SUB);
 #pragma nounroll
-    for (int p = 0; p < npass; p += 3) {
+    for (int p = 0; p < npass; p += sub + 1) {
 #pragma nounroll
-        for (int gi = 0; gi < 2; ++gi) gcl_pass2<PREC, TEAM, ATT>(v, pf);
+        for (int gi = 0; gi < sub; ++gi) gcl_pass2<PREC, TEAM, ATT>(v, pf);
         equiv_pass2<PREC, TEAM>(v, pf);
     }
     prof_event(pf, w, lane, 3);
@@ -1638,7 +1645,8 @@ __device__ __forceinline__ void ctx_store(const Lds& v, const ModelDims& md, int
     v.misc[CX_FLAGS] = (md.attention ? 1 : 0) | (md.tanh ? 2 : 0) | (md.mean ? 4 : 0);
     v.misc[CX_NORMC] = __float_as_int(md.norm_constant); v.misc[CX_CRANGE] = __float_as_int(md.coords_range);
     v.misc[CX_INVNORM] = __float_as_int(md.inv_norm);
-    v.misc[CX_NPASS] = 3 * md.n_layers; v.misc[CX_NF] = md.nf; v.misc[CX_FIN] = md.fin;
+    v.misc[CX_NPASS] = (md.sub + 1) * md.n_layers; v.misc[CX_NF] = md.nf; v.misc[CX_FIN] = md.fin;
+    v.misc[CX_SUB] = md.sub; v.misc[CX_CT] = md.ct;
     v.misc[CX_TFEAT] = __float_as_int(tfeat); v.misc[CX_MOL] = mol;
 }
 
@@ -2206,10 +2214,12 @@ const char* dl_error_string(int32_t s) {
 
 static int32_t check_cfg(const dl_config* c) {
     if (!c) return DL_ERR_BAD_ARG;
-    if (c->n_dims != 3 || c->hidden_nf != HID || c->inv_sublayers != 2 || c->condition_time != 1) return DL_ERR_UNSUPPORTED;
+    if (c->n_dims != 3 || c->hidden_nf != HID) return DL_ERR_UNSUPPORTED;
+    if (c->inv_sublayers < 1 || c->inv_sublayers > MAX_SUBLAYERS) return DL_ERR_UNSUPPORTED;
+    if ((c->condition_time | 1) != 1) return DL_ERR_BAD_ARG;
     if (c->in_node_nf < 1 || 3 + c->in_node_nf > DMAX || c->in_node_nf > 16) return DL_ERR_UNSUPPORTED;
     if (c->context_node_nf < 0 || c->context_node_nf > CTXMAX) return DL_ERR_UNSUPPORTED;
-    if (c->in_node_nf + 1 + c->context_node_nf > FINP) return DL_ERR_UNSUPPORTED;
+    if (c->in_node_nf + c->condition_time + c->context_node_nf > FINP) return DL_ERR_UNSUPPORTED;
     if (c->n_layers < 1 || c->n_layers > 64) return DL_ERR_UNSUPPORTED;
     if (!(c->normalization_factor > 0.0f)) return DL_ERR_BAD_ARG;
     if (c->precision != DL_PRECISION_FP32 && c->precision != DL_PRECISION_F16X3 && c->precision != DL_PRECISION_F16X2) return DL_ERR_UNSUPPORTED;
@@ -2221,7 +2231,7 @@ static int32_t check_cfg(const dl_config* c) {
 
 int32_t dl_model_num_tensors(const dl_config* cfg) {
     if (!cfg) return DL_ERR_BAD_ARG;
-    return 4 + cfg->n_layers * (2 * (8 + (cfg->attention ? 2 : 0)) + 5);
+    return 4 + cfg->n_layers * (cfg->inv_sublayers * (8 + (cfg->attention ? 2 : 0)) + 5);
 }
 
 int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_tensors, dl_model** out) {
@@ -2230,8 +2240,8 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     if (!w || !out || n_tensors != dl_model_num_tensors(cfg)) return DL_ERR_BAD_ARG;
     for (int i = 0; i < n_tensors; ++i)
         if (!w[i]) return DL_ERR_BAD_ARG;
-    const int nf = cfg->in_node_nf, fin = nf + 1 + cfg->context_node_nf, L = cfg->n_layers;
-    const size_t total = size_t(OFF_BLOCKS) + size_t(L) * BLOCK_SIZE;
+    const int nf = cfg->in_node_nf, fin = nf + cfg->condition_time + cfg->context_node_nf, L = cfg->n_layers, SUB = cfg->inv_sublayers;
+    const size_t total = size_t(OFF_BLOCKS) + size_t(L) * block_size(SUB);
     float* hp = static_cast<float*>(calloc(total, sizeof(float)));
     if (!hp) return DL_ERR_ALLOC;
     const bool f16 = cfg->precision != DL_PRECISION_FP32;
@@ -2261,8 +2271,8 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     std::vector<float> w1p, b1p, w2p, w3p, b3p, w4p;
     std::vector<double> proxy(HID);
     for (int blk = 0; blk < L; ++blk) {
-        float* base = hp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
-        for (int gi = 0; gi < 2; ++gi) {
+        float* base = hp + OFF_BLOCKS + size_t(blk) * block_size(SUB);
+        for (int gi = 0; gi < SUB; ++gi) {
             float* g = base + gi * GCL_SIZE;
             const float* w1 = w[ti++]; const float* b1 = w[ti++];     // edge_mlp.0 [128][258]
             const float* w2 = w[ti++]; const float* b2 = w[ti++];     // edge_mlp.2 [128][128]
@@ -2340,7 +2350,7 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
             sc[17] = vec_absmax_weighted(vv + 0 * HID, be); sc[18] = vec_absmax_weighted(vv + 4 * HID, bt);
             sc[19] = vec_absmax(vv + 5 * HID) * 1.0001f;
         }
-        float* e = base + 2 * GCL_SIZE;
+        float* e = base + SUB * GCL_SIZE;
         const float* w5 = w[ti++]; const float* b5 = w[ti++];         // coord_mlp.0 [128][258]
         const float* w6 = w[ti++]; const float* b6 = w[ti++];         // coord_mlp.2 [128][128]
         const float* w7 = w[ti++];                                    // coord_mlp.4 [1][128], no bias
@@ -2390,10 +2400,9 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
     m->cfg = *cfg;
     if (cfg->sin_embedding)
         for (int blk = 0; blk < L; ++blk) {
-            const float* base = hp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
-            m->sin_l1[blk * 3 + 0] = base[G_SCALE + 20];
-            m->sin_l1[blk * 3 + 1] = base[GCL_SIZE + G_SCALE + 20];
-            m->sin_l1[blk * 3 + 2] = base[2 * GCL_SIZE + E_SCALE + 11];
+            const float* base = hp + OFF_BLOCKS + size_t(blk) * block_size(SUB);
+            for (int gi = 0; gi < SUB; ++gi) m->sin_l1[blk * (MAX_SUBLAYERS + 1) + gi] = base[gi * GCL_SIZE + G_SCALE + 20];
+            m->sin_l1[blk * (MAX_SUBLAYERS + 1) + SUB] = base[SUB * GCL_SIZE + E_SCALE + 11];
         }
     m->n_floats = total;
     int ndev = 0;

@@ -30,7 +30,7 @@ constexpr int EDGE_THREADS = 256;
 
 struct PkDims {
     int B, N, V;                         // V = B*N padded atoms
-    int nf, ctx, fin, D;
+    int nf, ctx, fin, D, ct;             // ct: condition_time (the time feature joins the node inputs)
     int graph_type;                      // 0: '4A', 1: 'FC-4A', 2: 'FC-10A-4A', 3: fully connected with an int8 edge mask
     const int8_t* emask;                 // graph_type 3: [B,N,N] mask values (0: no edge; the value weights the message)
     float norm_constant;
@@ -122,8 +122,8 @@ __global__ void pk_init_kernel(PkDims d, PkWs w, const float* __restrict__ wp, c
     for (int k = 0; k < d.fin; ++k) {
         float hin;
         if (k < d.nf) hin = z[3 + k] * nm;
-        else if (k == d.nf) hin = t[size_t(b) * t_stride];      // time feature is not masked (egnn.py:501-509)
-        else hin = context[size_t(v) * d.ctx + (k - d.nf - 1)];
+        else if (k < d.nf + d.ct) hin = t[size_t(b) * t_stride];      // time feature is not masked (egnn.py:501-509)
+        else hin = context[size_t(v) * d.ctx + (k - d.nf - d.ct)];
         acc = fmaf(wrow[k], hin, acc);
     }
     w.H[size_t(v) * HID + f] = acc;
@@ -880,7 +880,7 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
     hipStream_t st = static_cast<hipStream_t>(stream_);
     const ModelDims md = dims_of(m);
     PkDims d;
-    d.B = B; d.N = N; d.V = B * N; d.nf = md.nf; d.ctx = md.ctx; d.fin = md.fin; d.D = 3 + md.nf;
+    d.B = B; d.N = N; d.V = B * N; d.nf = md.nf; d.ctx = md.ctx; d.fin = md.fin; d.D = 3 + md.nf; d.ct = md.ct;
     d.graph_type = graph_type; d.norm_constant = md.norm_constant; d.emask = emask;
     const bool weighted = graph_type == 3;
     const PkWs w = carve(workspace, B, N);
@@ -944,23 +944,24 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
     // sin_embedding: the largest row L1 norm of the embedded-distance columns bounds their term (host copy of the pass's scale slot)
     auto wg_bound = [&](int blk, int which) -> float {
         if (!md.sin) return 0.0f;
-        return m->sin_l1[size_t(blk) * 3 + which];
+        return m->sin_l1[size_t(blk) * (MAX_SUBLAYERS + 1) + which];
     };
     for (int blk = 0; blk < md.n_layers; ++blk) {
-        const float* base = wp + OFF_BLOCKS + size_t(blk) * BLOCK_SIZE;
-        const float* g0 = base;
-        const float* g1 = base + GCL_SIZE;
-        const float* eq = base + 2 * GCL_SIZE;
+        const float* base = wp + OFF_BLOCKS + size_t(blk) * block_size(md.sub);
+        const float* eq = base + md.sub * GCL_SIZE;
         // projections for gcl_0 (the previous block's node kernel already produced them, except for block 0)
-        if (blk == 0) node(nullptr, g0, false);
-        edge(false, g0 + G_W2, g0 + G_VEC + HID, g0 + G_SCALE, 5, g0 + G_VEC + 6 * HID, 0.0f, g0 + G_WG, wg_bound(blk, 0));
-        node(g0, g1, false);
-        edge(false, g1 + G_W2, g1 + G_VEC + HID, g1 + G_SCALE, 5, g1 + G_VEC + 6 * HID, 0.0f, g1 + G_WG, wg_bound(blk, 1));
-        node(g1, eq, true);
-        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2, nullptr, md.tanh ? md.coords_range : 0.0f, eq + E_WG, wg_bound(blk, 2));
+        if (blk == 0) node(nullptr, base, false);
+        for (int gi = 0; gi < md.sub; ++gi) {                      // inv_sublayers GCLs (2 in every released configuration) ...
+            const float* g = base + gi * GCL_SIZE;
+            edge(false, g + G_W2, g + G_VEC + HID, g + G_SCALE, 5, g + G_VEC + 6 * HID, 0.0f, g + G_WG, wg_bound(blk, gi));
+            if (gi + 1 < md.sub) node(g, g + GCL_SIZE, false);
+            else node(g, eq, true);
+        }
+        // ... then the equivariant update
+        edge(true, eq + E_W6, eq + E_VEC + HID, eq + E_SCALE, 2, nullptr, md.tanh ? md.coords_range : 0.0f, eq + E_WG, wg_bound(blk, md.sub));
         hipLaunchKernelGGL(pk_xupdate_kernel, dim3((V + 255) / 256), dim3(256), 0, st, d, w, linker_mask);
         if (blk + 1 < md.n_layers) {
-            const float* n0 = base + BLOCK_SIZE;                   // next block's gcl_0 projections (h unchanged)
+            const float* n0 = base + block_size(md.sub);           // next block's gcl_0 projections (h unchanged)
             node(nullptr, n0, false);
         }
     }

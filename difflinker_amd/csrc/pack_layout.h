@@ -9,7 +9,7 @@ struct dl_model {
     dl_config cfg;
     float* d_pack;
     size_t n_floats;
-    float sin_l1[64 * 3];           // sin_embedding: per block, row L1 bound of the embedded-distance columns of gcl_0, gcl_1, gcl_equiv
+    float sin_l1[64 * 5];           // sin_embedding: per block, row L1 bound of the embedded-distance columns of gcl_0 .. gcl_{k-1}, gcl_equiv (k = inv_sublayers <= 4)
 };
 
 namespace {
@@ -62,10 +62,12 @@ constexpr int ES_WRW = 32, ES_WDW = 33;
 constexpr int E_SCALE_SIZE = 48;
 constexpr int E_WG = E_SCALE + E_SCALE_SIZE;         // sin_embedding: the same for coord_mlp.0
 constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + E_SCALE_SIZE + SIN_K * HID;
-constexpr int BLOCK_SIZE = 2 * GCL_SIZE + EQ_SIZE;
+constexpr int MAX_SUBLAYERS = 4;                     // inv_sublayers: GCLs per block (reference default and every released config: 2)
+__host__ __device__ inline size_t block_size(int sublayers) { return size_t(sublayers) * GCL_SIZE + EQ_SIZE; }
 
 struct ModelDims {
     int nf, ctx, fin, n_layers;
+    int sub, ct;                        // inv_sublayers (GCLs per block); condition_time (0 / 1: the time feature joins the node inputs)
     float norm_constant;
     int attention, tanh, mean, sin;     // optional hyper-parameters (sin_embedding: the HBM-resident kernels only)
     float coords_range, inv_norm;
@@ -75,8 +77,10 @@ inline ModelDims dims_of(const dl_model* m) {
     ModelDims md;
     md.nf = m->cfg.in_node_nf;
     md.ctx = m->cfg.context_node_nf;
-    md.fin = md.nf + 1 + md.ctx;
+    md.ct = m->cfg.condition_time ? 1 : 0;
+    md.fin = md.nf + md.ct + md.ctx;
     md.n_layers = m->cfg.n_layers;
+    md.sub = m->cfg.inv_sublayers;
     md.norm_constant = m->cfg.norm_constant;
     md.attention = m->cfg.attention; md.tanh = m->cfg.tanh; md.mean = m->cfg.aggregation_mean; md.sin = m->cfg.sin_embedding;
     md.coords_range = m->cfg.coords_range; md.inv_norm = 1.0f / m->cfg.normalization_factor;

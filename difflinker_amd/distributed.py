@@ -99,11 +99,9 @@ def sample_chain_sharded(edm, inputs, keep_frames=None, noise_bank=None, group=N
     materialises the global bank, and a sample does not depend on the world size); every rank must hold the same
     ``edm.noise_seed``.  ``edm.noise_source = 'torch'`` is honoured only when the caller hands over the global
     ``noise_bank`` explicitly (parity tests): drawing the reference's ``torch.randn`` stream for the whole batch on every
-    rank costs the full bank (2.5 GB at config C3) and the full ``randn`` work per GPU."""
-    from .edm import InpaintingEDM
-    if isinstance(edm, InpaintingEDM):
-        raise NotImplementedError('sample_chain_sharded drives EDM.sample_chain; InpaintingEDM draws a different noise '
-                                  'sequence (p and q draws per step) and is not wired to the sharded entry point')
+    rank costs the full bank (2.5 GB at config C3) and the full ``randn`` work per GPU.
+    ``InpaintingEDM`` (edm.py:549-730) is sharded the same way (round 5): its ``1 + 2T + 2`` draws per molecule come from the
+    same counter-based generator, keyed by the global molecule index; its centre-of-gravity projections are per molecule."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     bs, n = inputs['x'].shape[0], inputs['x'].shape[1]

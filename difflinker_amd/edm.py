@@ -489,20 +489,21 @@ class EDM(torch.nn.Module):
         self._raise_on_chain_flags(flags, steps)
         return chain
 
-    def philox_noise_bank(self, n_samples, n_nodes, device, mol_offset=0, seed=None):
-        """The in-kernel stream as a bank ``(noise_x [T+2,B,N,3], noise_h [T+2,B,N,nf])`` (``dl_philox_fill``); advances
-        ``noise_seed`` unless ``seed`` is given."""
+    def philox_noise_bank(self, n_samples, n_nodes, device, mol_offset=0, seed=None, n_draws=None):
+        """The in-kernel stream as a bank ``(noise_x [T+2,B,N,3], noise_h [T+2,B,N,nf])`` (``dl_philox_fill``; ``n_draws``: another
+        number of draws); advances ``noise_seed`` unless ``seed`` is given."""
         if torch.device(device).type != 'cuda':
             raise RuntimeError('the Philox noise bank is generated on the GPU (no CPU fallback)')
         if seed is None:
             seed = int(self.noise_seed)
             self.noise_seed = seed + 1
-        noise_x = torch.empty((self.T + 2, n_samples, n_nodes, self.n_dims), device=device)
-        noise_h = torch.empty((self.T + 2, n_samples, n_nodes, self.in_node_nf), device=device)
+        n_draws = self.T + 2 if n_draws is None else int(n_draws)
+        noise_x = torch.empty((n_draws, n_samples, n_nodes, self.n_dims), device=device)
+        noise_h = torch.empty((n_draws, n_samples, n_nodes, self.in_node_nf), device=device)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(_lib.load().dl_philox_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(mol_offset), None, n_samples, n_nodes,
-                                                  self.in_node_nf, 0, self.T + 2, noise_x.data_ptr(), noise_h.data_ptr(),
+                                                  self.in_node_nf, 0, n_draws, noise_x.data_ptr(), noise_h.data_ptr(),
                                                   ctypes.c_void_p(stream)), 'dl_philox_fill')
         return noise_x, noise_h
 
@@ -650,12 +651,15 @@ class InpaintingEDM(EDM):
     @torch.no_grad()
     def sample_chain(self, x, h, node_mask, edge_mask, fragment_mask, linker_mask, context, keep_frames=None,
                      noise_bank=None, mol_offset=0):
-        """``InpaintingEDM.sample_chain`` (edm.py:549-610).  Noise: the reference's ``torch.randn`` sequence (or an explicit
-        bank of ``1 + 2T + 2`` draws); the counter-based in-kernel stream is not defined for the p/q draw pairs of this
-        sampler, so ``noise_source='philox'`` / ``mol_offset`` raise instead of being silently ignored."""
-        if (self.noise_source == 'philox' and noise_bank is None) or mol_offset:
-            raise NotImplementedError("InpaintingEDM draws the reference's torch.randn stream (or an explicit noise_bank); "
-                                      "noise_source='philox' / mol_offset are EDM.sample_chain features")
+        """``InpaintingEDM.sample_chain`` (edm.py:549-610).  Noise: the reference's ``torch.randn`` sequence, an explicit bank of
+        ``1 + 2T + 2`` draws (initial z, then the p and q draw of every step, then the two of the decode), or - round 5 -
+        ``noise_source='philox'``: that bank generated on the device from (``noise_seed``, GLOBAL molecule index = ``mol_offset`` +
+        row, atom, draw), so a shard of a batch samples what the whole batch would (``distributed.sample_chain_sharded``); the
+        ``torch.randn`` stream cannot be sharded (``mol_offset`` raises with it)."""
+        philox = noise_bank is None and self.noise_source == 'philox'
+        if mol_offset and not philox and noise_bank is None:
+            raise NotImplementedError("a shard of a batch (mol_offset) needs noise_source='philox' or the shard's rows of an explicit "
+                                      'noise_bank: the torch.randn stream is a property of the whole batch')
         dev = x.device
         if dev.type != 'cuda':
             raise RuntimeError('difflinker_amd.InpaintingEDM.sample_chain runs on the GPU only (HIP kernels, no CPU fallback)')
@@ -666,14 +670,21 @@ class InpaintingEDM(EDM):
         nf, T = self.in_node_nf, self.T
         keep_frames = T if keep_frames is None else keep_frames
         assert keep_frames <= T
-        if noise_bank is None:
+        if philox:
+            noise_x, noise_h = self.philox_noise_bank(bs, n, dev, mol_offset=mol_offset, n_draws=1 + 2 * T + 2)
+        elif noise_bank is None:
             noise_x, noise_h = self.draw_inpainting_noise_bank(bs, n, dev)
         else:
             noise_x, noise_h = (t_.to(dev, torch.float32).contiguous() for t_ in noise_bank)
             assert noise_x.shape[0] == 1 + 2 * T + 2
-        # (the draws are fixed: a team of workgroups that cannot assemble means one more run on one compute unit per molecule)
-        return self.dynamics.without_teams(lambda: self._inpaint_chain(x, h, node_mask, edge_mask, fragment_mask, linker_mask, context,
-                                                                       keep_frames, noise_x, noise_h))
+        # (the draws are fixed: a team of workgroups that cannot assemble means one more run on one compute unit per molecule;
+        # team sizes follow the WHOLE batch when this is a shard of one: EDM.team_batch)
+        self.dynamics.team_batch = bs if self.team_batch is None else max(bs, int(self.team_batch))
+        try:
+            return self.dynamics.without_teams(lambda: self._inpaint_chain(x, h, node_mask, edge_mask, fragment_mask, linker_mask,
+                                                                           context, keep_frames, noise_x, noise_h))
+        finally:
+            self.dynamics.team_batch = None
 
     def _inpaint_chain(self, x, h, node_mask, edge_mask, fragment_mask, linker_mask, context, keep_frames, noise_x, noise_h):
         lib = _lib.load()

@@ -145,6 +145,43 @@ def egnn_tensor_order(n_layers, inv_sublayers=2, attention=False):
     return keys
 
 
+HIDDEN_WIDTH = 128          # hidden_nf of the kernels (MFMA tiles of 4 x 32 features, the LDS layout of egnn_fc.hip)
+
+
+def pad_to_kernel_width(key, t, hidden_nf, width=HIDDEN_WIDTH):
+    """A tensor of a ``hidden_nf <= 128`` EGNN as the tensor of the 128-wide network that computes the same function: the extra
+    hidden features get zero weights in and out (and zero biases), SiLU(0) = 0, so they never carry a value - every sum the
+    kernels form gains exact zeros only.  ``edge_mlp.0`` / ``coord_mlp.0`` [h, 2h + e] -> [128, 256 + e] (sender block moved to
+    column 128, the e distance columns to 256), ``node_mlp.0`` [h, 2h] -> [128, 256] (aggregate block to column 128)."""
+    h = hidden_nf
+    if h == width:
+        return t.contiguous()
+    if key.endswith('.bias'):
+        if key.startswith('embedding_out') or 'att_mlp' in key:
+            return t.contiguous()
+        out = t.new_zeros(width)
+        out[:h] = t
+        return out
+    if key == 'embedding.weight':                       # [h, fin]
+        out = t.new_zeros(width, t.shape[1]); out[:h] = t; return out
+    if key == 'embedding_out.weight':                   # [fin, h]
+        out = t.new_zeros(t.shape[0], width); out[:, :h] = t; return out
+    if key.endswith('edge_mlp.0.weight') or key.endswith('coord_mlp.0.weight'):
+        e = t.shape[1] - 2 * h
+        out = t.new_zeros(width, 2 * width + e)
+        out[:h, :h] = t[:, :h]; out[:h, width:width + h] = t[:, h:2 * h]; out[:h, 2 * width:] = t[:, 2 * h:]
+        return out
+    if key.endswith('node_mlp.0.weight'):
+        out = t.new_zeros(width, 2 * width)
+        out[:h, :h] = t[:, :h]; out[:h, width:width + h] = t[:, h:]
+        return out
+    if key.endswith('att_mlp.0.weight') or key.endswith('coord_mlp.4.weight'):      # [1, h]
+        out = t.new_zeros(1, width); out[:, :h] = t; return out
+    assert t.shape == (h, h), (key, tuple(t.shape))     # edge_mlp.2, node_mlp.2, coord_mlp.2
+    out = t.new_zeros(width, width); out[:h, :h] = t
+    return out
+
+
 class _HipModel:
     """Owner of one ``dl_model`` handle (packed weights in HBM of one device)."""
 
@@ -179,9 +216,10 @@ class Dynamics(nn.Module):
         # chain kernel is not used).  No released configuration uses any of them.
         if aggregation_method not in ('sum', 'mean'): unsupported.append(f'aggregation_method={aggregation_method!r}')
         if not isinstance(activation, nn.SiLU): unsupported.append(f'activation={activation!r}')
-        if hidden_nf != 128: unsupported.append(f'hidden_nf={hidden_nf}')
-        if inv_sublayers != 2: unsupported.append(f'inv_sublayers={inv_sublayers}')
-        if not condition_time: unsupported.append('condition_time=False')
+        # round 5: hidden_nf <= 128 (the reference's own default is 64) runs on the 128-wide kernels with the weights zero-padded -
+        # exactly the narrower network, SiLU(0) = 0; inv_sublayers 1..4 and condition_time=False run natively
+        if not 1 <= hidden_nf <= 128: unsupported.append(f'hidden_nf={hidden_nf} (the kernels are 128 wide)')
+        if not 1 <= inv_sublayers <= 4: unsupported.append(f'inv_sublayers={inv_sublayers}')
         if n_dims != 3: unsupported.append(f'n_dims={n_dims}')
         if unsupported:
             raise NotImplementedError('hyper-parameters outside the HIP path (released configs use none of them): '
@@ -206,6 +244,7 @@ class Dynamics(nn.Module):
             normalization_factor=normalization_factor, aggregation_method=aggregation_method, attention=attention,
             tanh=tanh, sin_embedding=sin_embedding)
         self.n_layers = n_layers
+        self.inv_sublayers = inv_sublayers
         self.edge_cache = {}                           # kept for attribute parity; the kernels need no edge list
         self._hip_models = {}                          # device index -> (_HipModel, weight version)
         # arithmetic of the 128-wide GEMMs (not a reference hyper-parameter): 'f16x3' = scaled split-fp16 on the
@@ -242,8 +281,8 @@ class Dynamics(nn.Module):
 
     def hip_config(self):
         return _lib.DLConfig(n_dims=self.n_dims, in_node_nf=self.in_node_nf, context_node_nf=self.context_node_nf,
-                             hidden_nf=self.dynamics.hidden_nf, n_layers=self.n_layers, inv_sublayers=2,
-                             condition_time=1, norm_constant=float(self.norm_constant),
+                             hidden_nf=HIDDEN_WIDTH, n_layers=self.n_layers, inv_sublayers=int(self.inv_sublayers),
+                             condition_time=int(bool(self.condition_time)), norm_constant=float(self.norm_constant),
                              normalization_factor=float(self.normalization_factor),
                              precision=_lib.PRECISIONS[self.precision], attention=int(self.attention), tanh=int(self.tanh),
                              coords_range=15.0, aggregation_mean=int(self.aggregation_method == 'mean'),
@@ -261,8 +300,8 @@ class Dynamics(nn.Module):
         if cached is not None and cached[1] == version:
             return cached[0].handle
         sd = self.dynamics.state_dict()
-        host = [sd[k].detach().to('cpu', torch.float32).contiguous()
-                for k in egnn_tensor_order(self.n_layers, attention=self.attention)]
+        host = [pad_to_kernel_width(k, sd[k].detach().to('cpu', torch.float32), self.dynamics.hidden_nf)
+                for k in egnn_tensor_order(self.n_layers, inv_sublayers=self.inv_sublayers, attention=self.attention)]
         cfg = self.hip_config()
         assert lib.dl_model_num_tensors(ctypes.byref(cfg)) == len(host)
         arr = (ctypes.c_void_p * len(host))(*[t.data_ptr() for t in host])
