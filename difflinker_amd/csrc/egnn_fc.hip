@@ -80,6 +80,7 @@ constexpr int TM_ROWS = 4;       // exchange rows of this molecule (device point
 constexpr int TM_FLAGS = 6;      // arrival words of this molecule's workgroups (device pointer: lo, hi)
 constexpr int TM_S = 8, TM_RANK = 9, TM_NOWN = 10;   // team size, own index, number of own atoms (one workgroup: 1, 0, n_b)
 constexpr int MS_NRCV = 12;      // (every kernel) length of the coordinate-pass receiver list v.rcv
+constexpr int MS_FULL = 13;      // (every kernel) the receiver list holds EVERY own atom (no linker mask, or a skipped sum could not be proven finite)
 
 struct Lds {
     float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag;
@@ -1181,7 +1182,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 12);
-    if (PREC != 0 && tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
+    if (tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }      // (max |h| is kept in every arithmetic mode: equiv_pass2's finiteness proof)
     float sa = 1.0f, accs = 1.0f;
     if (PREC != 0) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);     // senders: any atom of the molecule
@@ -1312,7 +1313,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) hs[HS_HO + ((4 * mt + nt) * 16 + reg) * 64 + lane] = hnew[reg];
         }
-        if (PREC != 0) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
+        block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
     }
     if (tid == 0) {
         if (PREC != 0) v.fmax[FS_HS] = __float_as_uint(s_hn);
@@ -1331,6 +1332,16 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     open_pass<PREC, TEAM>(v, nb, nown, nx, hs, pf, pw, cx.pass + 1, par ^ 1);
 }
 
+// every own atom becomes a receiver of the coordinate pass (equiv_pass2: a skipped sum could not be proven finite); the caller's
+// barrier follows
+__device__ __forceinline__ void receivers_all(const Lds& v, int nown, int tid) {
+    if (tid < NMAX + 1) {
+        if (tid < nown) v.rcv[tid] = tid;
+        v.rpos[tid] = tid < nown ? tid : -1;
+    }
+    if (tid == 0) { v.misc[MS_NRCV] = nown; v.misc[MS_FULL] = 1; }
+}
+
 // EquivariantUpdate (egnn.py:101-125), per-atom phases version 2: the h fragment rows in v.C survive the pass; P, Q of
 // this pass are in place (open_pass); ends with the next pass opened.
 template <int PREC, bool TEAM>
@@ -1345,12 +1356,28 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     const int w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
-    if (PREC != 0) {
+    {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
-        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, ES_WRW) + x02 * cload(sc, ES_WDW)));
-        accs = sa * cload(sc, 2);
+        const float u1b = pqb + 4.0f * (x2 * cload(sc, ES_WRW) + x02 * cload(sc, ES_WDW));        // >= every hidden activation of this pass
+        if (PREC != 0) {
+            sa = scale_for(u1b);
+            accs = sa * cload(sc, 2);
+        }
+        // The pass runs for the receivers inside the linker mask only: the reference multiplies every other atom's sum by zero
+        // (egnn.py:113-116).  That is the reference's result exactly as long as the skipped sums are FINITE - an inf or NaN there
+        // becomes NaN * 0 = NaN in the reference's coordinates (and FoundNaNException).  The bound of the head's output proves it:
+        // |trans| <= |coord_diff| |w7' . u2| <= phi, at most nb terms of mask weight <= 2 per sum.  Where it does not (an
+        // overflowing head, non-finite features: the comparison is false for inf and NaN), the receiver list becomes every own
+        // atom - for the rest of the launch - and the sums are formed and multiplied by the mask as the reference does.
+        const float phi = cload(sc, ES_W7L1) * fmaf(cload(sc, ES_L1_W6), u1b, cload(sc, ES_B6));
+        const bool proven = 2.0f * float(nb) * phi < 1e37f;
+        if (!proven && ctx_i(v, MS_FULL) == 0) {
+            const int tid_ = q.tid;
+            receivers_all(v, TEAM ? ctx_i(v, TM_NOWN) : nb, tid_);
+            __syncthreads();
+        }
     }
     pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
                                         (cx.flags & 2) ? ctx_f(v, CX_CRANGE) : 0.0f, pf);      // ends with the partial triples in LDS
@@ -1372,7 +1399,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
     const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
     pair_reduce_equiv(v, nown, nb, tid, xscale);
-    if (TEAM && PREC != 0 && tid == 0) v.fmax[FM_XOWN] = 0u;
+    if (TEAM && tid == 0) v.fmax[FM_XOWN] = 0u;
     lds_barrier();                         // partials read: P, Q, W2' regions are free
     stage_next(v, nx, w, tid);
     if constexpr (TEAM) {
@@ -1380,7 +1407,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
             for (int e = tid; e < nown * 32; e += THREADS)
                 *reinterpret_cast<float4*>(v.C + (e >> 5) * LDH + 4 * (e & 31)) = *reinterpret_cast<const float4*>(hs + HS_HF + (e >> 5) * HID + 4 * (e & 31));
     } else {
-        if (PREC != 0 && tid == 0) v.fmax[FM_X2] = 0u;
+        if (tid == 0) v.fmax[FM_X2] = 0u;
         lds_barrier();
     }
     float n2 = 0.0f;
@@ -1398,7 +1425,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
             n2 = fmaf(xn, xn, n2);
         }
     }
-    if (PREC != 0) block_max(&v.fmax[TEAM ? FM_XOWN : FM_X2], n2, lane);       // (a team: the own atoms; the exchange headers carry it)
+    block_max(&v.fmax[TEAM ? FM_XOWN : FM_X2], n2, lane);       // (a team: the own atoms; the exchange headers carry it)
     prof_event(pf, w, lane, 34);
     lds_barrier();
     prof_event(pf, w, lane, 10);
@@ -1427,7 +1454,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
     if (tid < 8) reinterpret_cast<int*>(v.A - L_A + L_PROG)[tid] = 0;      // pair-loop progress slots (pair_phase); barriers follow
     prof_event(pf, w, lane, 1);
-    if (PREC != 0) {
+    {
         if (tid < 8) v.fmax[tid] = 0u;
         __syncthreads();
     }
@@ -1441,7 +1468,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         v.xs[4 * a + k] = xv;
         v.x0[4 * a + k] = xv;
     }
-    if (PREC != 0) {                           // max |x|^2 at entry (a team: of the own atoms, for its first exchange header)
+    {                                          // max |x|^2 at entry (a team: of the own atoms, for its first exchange header)
         float n2 = 0.0f;
         if (tid < nown) {
             const float x0 = v.z[tid * DMAX], x1 = v.z[tid * DMAX + 1], x2 = v.z[tid * DMAX + 2];
@@ -1486,7 +1513,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
             }
             hmax = fmaxf(hmax, fabsf(acc));
         }
-        if (PREC != 0) block_max(&v.fmax[FM_H0], hmax, lane);
+        block_max(&v.fmax[FM_H0], hmax, lane);
     }
     __syncthreads();
     {   // fragment rows of the embedded h -> v.C
@@ -1565,7 +1592,7 @@ __device__ __forceinline__ void build_receivers(const Lds& v, int nown, int tid)
         const int pos = __popcll(bal & ((1ull << tid) - 1ull));
         if (rec) v.rcv[pos] = tid;
         if (tid < NMAX + 1) v.rpos[tid] = rec ? pos : -1;
-        if (tid == 0) v.misc[MS_NRCV] = __popcll(bal);
+        if (tid == 0) { v.misc[MS_NRCV] = __popcll(bal); v.misc[MS_FULL] = (__popcll(bal) == nown) ? 1 : 0; }
     }
 }
 
@@ -2394,6 +2421,14 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         sc[ES_WDW] = vec_absmax_weighted(vv + 2 * HID, bc);
         sc[8] = row_l1_weighted(w1p.data(), ld5, 0, HID, c, bc); sc[9] = row_l1_weighted(w1p.data(), ld5, HID, HID, c, bc);
         sc[10] = vec_absmax_weighted(vv + 0 * HID, bc);
+        // bound of the head's output (every arithmetic mode): the second layer on the operands as they enter it, then w7'
+        sc[ES_L1_W6] = row_l1(w2p.data(), HID, 0, 1.0);
+        sc[ES_B6] = vec_absmax(vv + 3 * HID) * 1.0001f;
+        {
+            double l1 = 0.0;
+            for (int f = 0; f < HID; ++f) l1 += fabs(double(vv[4 * HID + f]));
+            sc[ES_W7L1] = float(l1 * 1.0001);
+        }
     }
     dl_model* m = static_cast<dl_model*>(calloc(1, sizeof(dl_model)));
     if (!m) { free(hp); return DL_ERR_ALLOC; }

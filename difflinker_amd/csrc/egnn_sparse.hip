@@ -85,6 +85,18 @@ inline PkWs carve(void* base, int B, int N) {
     return w;
 }
 
+// words of PkWs.total: [0] quads, [1] tiles of the coordinate pass, [2] "this coordinate pass runs over EVERY tile" (written by its
+// edge kernel, read by pk_xupdate_kernel), [4..6] float bits of the batch-wide maxima of |h|, |x|^2, |x0|^2 (atomicMax; never reset
+// inside a forward: conservative) - what the proof behind skipping the masked coordinate sums needs (pk_edge_kernel<EQUIV>)
+constexpr int TW_FULL = 2, TW_HMAX = 4, TW_X2 = 5, TW_X02 = 6;
+// batch-wide maximum of non-negative floats (as bits: they order like the values, NaN above all): the atomic is issued only when
+// the word - read relaxed, possibly stale, i.e. LOWER - does not already hold as much; after the first few waves of a kernel nobody
+// issues one (19 k atoms x 128 features of atomics on ONE address cost a forward of the pocket configuration a third of its time)
+__device__ __forceinline__ void gmax_update(int* total, int word, float val) {
+    unsigned* p = reinterpret_cast<unsigned*>(total) + word;
+    const unsigned bits = __float_as_uint(val);
+    if (bits > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, bits);
+}
 // atom flags
 constexpr int F_REAL = 1, F_LIG = 2, F_POCK = 4, F_MOVES = 8;   // F_MOVES: linker mask != 0, the only atoms whose coordinates change
 
@@ -107,6 +119,11 @@ __global__ void pk_init_kernel(PkDims d, PkWs w, const float* __restrict__ wp, c
         w.X[4 * v + f] = xv;
         w.X0[4 * v + f] = xv;
     }
+    if (f == 5) {
+        const float n2 = (z[0] * z[0] + z[1] * z[1] + z[2] * z[2]) * nm;
+        gmax_update(w.total, TW_X2, n2);
+        gmax_update(w.total, TW_X02, n2);
+    }
     if (f == 4) {
         bool lig = false, pock = false;
         if (d.graph_type != 3) {
@@ -127,6 +144,11 @@ __global__ void pk_init_kernel(PkDims d, PkWs w, const float* __restrict__ wp, c
         acc = fmaf(wrow[k], hin, acc);
     }
     w.H[size_t(v) * HID + f] = acc;
+    {
+        float m = fabsf(acc);                                       // max |h| of the embedding, one atomic per 16 lanes
+        m = fmaxf(m, dpp_mov<0xB1>(m)); m = fmaxf(m, dpp_mov<0x4E>(m)); m = fmaxf(m, dpp_mov<0x141>(m)); m = fmaxf(m, dpp_mov<0x140>(m));
+        if ((threadIdx.x & 15) == 0) gmax_update(w.total, TW_HMAX, acc != acc ? acc : m);
+    }
 }
 
 // edge predicate of get_dist_edges / get_dist_edges_4A (egnn.py:554-596), i != j, same molecule
@@ -387,9 +409,10 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
             if (v < d.V) w.H[size_t(v) * HID + 32 * nt + c] = val;
             nmax = fmaxf(nmax, fabsf(val));
         }
-        if (PREC == 1) wg_max(&mx[3], nmax, lane);
+        wg_max(&mx[3], nmax, lane);
         __syncthreads();
         if (PREC == 1) s_h = scale_for(__uint_as_float(mx[3]));
+        if (tid == 0) gmax_update(w.total, TW_HMAX, __uint_as_float(mx[3]));       // batch-wide max |h| (pk_edge_kernel<EQUIV>)
     }
     if (pre_units) {
         // P (feature tile nt of W1a') and Q (feature tile nt of W1b') for the next edge pass
@@ -517,8 +540,24 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
     __shared__ __attribute__((aligned(16))) float Pst[EDGE_THREADS / 64][4 * LDT];   // row stride LDT: the four rows fall into different banks
     float* pst = Pst[wv];
     // work list: every tile (GCL), the tiles with a linker receiver (coordinate head)
-    auto tile_of = [&](int k) { return EQUIV ? w.eq_tiles[k] : k; };
-    const int nall = EQUIV ? w.total[1] : ntiles;
+    // The coordinate head runs over the tiles that hold a linker receiver only: the reference multiplies every other atom's sum by
+    // zero (egnn.py:113-116) - its result exactly, as long as the skipped sums are FINITE (an inf / NaN there is NaN * 0 = NaN in
+    // the reference's coordinates).  The bound of the head's output proves it from the batch-wide maxima of |h| and |x|^2
+    // (|trans| <= |w7' . u2| <= phi; at most N terms of mask weight <= 2 per sum); where it does not - an overflowing head,
+    // non-finite features: the comparison is false for inf and NaN - every tile is computed and pk_xupdate_kernel multiplies by
+    // the mask as the reference does.
+    bool full = false;
+    if constexpr (EQUIV) {
+        const unsigned* tw = reinterpret_cast<const unsigned*>(w.total);
+        const float hmax = __uint_as_float(tw[TW_HMAX]), x2 = __uint_as_float(tw[TW_X2]), x02 = __uint_as_float(tw[TW_X02]);
+        const float geo = SIN ? wg_l1 : 4.0f * (x2 * sc[ES_WRW] + x02 * sc[ES_WDW]);
+        const float u1b = (sc[8] + sc[9]) * hmax + sc[10] + geo;
+        const float phi = sc[ES_W7L1] * fmaf(sc[ES_L1_W6], u1b, sc[ES_B6]);
+        full = !(2.0f * float(d.N) * phi < 1e37f);
+        if (blockIdx.x == 0 && tid == 0) w.total[TW_FULL] = full ? 1 : 0;
+    }
+    auto tile_of = [&](int k) { return (EQUIV && !full) ? w.eq_tiles[k] : k; };
+    const int nall = (EQUIV && !full) ? w.total[1] : ntiles;
     const int wlo = int((long long)nall * xcd / 8), nwork = int((long long)nall * (xcd + 1) / 8);     // this XCD's part [wlo, nwork)
     int idx = wlo + gw;
     int t = idx < nwork ? tile_of(idx) : 0;
@@ -635,7 +674,11 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
                 const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(bound), __float_as_uint(bound), false, false);
                 bound = fmaxf(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
             }
-            const float sa = scale_for(__builtin_amdgcn_readfirstlane(bound));   // wave-uniform (both halves hold the same pairs)
+            // wave-uniform (both halves hold the same pairs).  (The BITS go through readfirstlane: until round 5 the float itself did,
+            // i.e. converted to int and back - a bound below 1 became 0 (scale 2^60: every activation saturated at the fp16 maximum)
+            // and one above 2^31 became 2^31; found by the magnitude sweep of scripts/r5/debug_range.py, pinned by
+            // tests/test_gpu_round5.py::test_hbm_resident_kernels_over_twenty_binades_of_magnitude)
+            const float sa = scale_for(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bound))));
             const float accs = sa * sc[sw_index], inv = inv_pow2(accs);
             // accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
             acc0 = splat16(0.0f); acc1 = splat16(0.0f); acc2 = splat16(0.0f); acc3 = splat16(0.0f);
@@ -805,7 +848,7 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
 __global__ void pk_xupdate_kernel(PkDims d, PkWs w, const float* __restrict__ linker_mask) {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= d.V) return;
-    if (!(w.flags[v] & F_MOVES)) return;                           // its tiles were not even computed (pk_eqtiles_kernel)
+    if (!(w.flags[v] & F_MOVES) && w.total[TW_FULL] == 0) return;  // its tiles were not even computed (pk_eqtiles_kernel; pk_edge_kernel<EQUIV>)
     const int q0 = w.tile_off[v], nq = w.ntile[v];
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (nq > 0) {
@@ -826,6 +869,7 @@ __global__ void pk_xupdate_kernel(PkDims d, PkWs w, const float* __restrict__ li
     float4 x = *reinterpret_cast<const float4*>(w.X + 4 * v);
     x.x = (x.x + ax * lm) * nm; x.y = (x.y + ay * lm) * nm; x.z = (x.z + az * lm) * nm;
     *reinterpret_cast<float4*>(w.X + 4 * v) = x;
+    gmax_update(w.total, TW_X2, x.x * x.x + x.y * x.y + x.z * x.z);
 }
 
 // 8. output head: h_final = (Wo h + bo)[:nf] * node_mask, vel = (x - x0) * node_mask, NaN flags per molecule
@@ -888,6 +932,7 @@ int32_t run_sparse(const dl_model* m, int32_t B, int32_t N, int32_t graph_type, 
     const int V = d.V;
 
     if (!ok(hipMemsetAsync(nan_flags, 0, size_t(B) * 4, st))) return DL_ERR_HIP;
+    if (!ok(hipMemsetAsync(w.total, 0, 256, st))) return DL_ERR_HIP;           // counters and batch-wide maxima (TW_*)
     hipLaunchKernelGGL(pk_init_kernel, dim3((V * HID + 255) / 256), dim3(256), 0, st, d, w, wp, xh, t,
                        t_is_scalar ? 0 : 1, node_mask, linker_mask, context);
     hipLaunchKernelGGL(pk_edges_kernel<false>, dim3((V + 3) / 4), dim3(256), 0, st, d, w);

@@ -59,6 +59,9 @@ constexpr int E_SCALE = E_VEC + 5 * HID;             // [2] sw(W6'), [6], [7] ma
 constexpr int ES_SW_W5A = 16, ES_SW_W5B = 20;        // 4 each: weight scale of output tile nt
 constexpr int ES_NE = 24;                            // 8: 2^n of k-slab s of the coordinate model's hidden layer
 constexpr int ES_WRW = 32, ES_WDW = 33;
+// every arithmetic mode: what bounds the coordinate head's output, |w7' . u2| <= ES_W7L1 * (ES_L1_W6 * max |u1| + ES_B6) - the kernels
+// skip the coordinate sums the linker mask multiplies by zero only while this proves them finite (egnn_fc.hip: equiv_pass2)
+constexpr int ES_L1_W6 = 34, ES_B6 = 35, ES_W7L1 = 36;
 constexpr int E_SCALE_SIZE = 48;
 constexpr int E_WG = E_SCALE + E_SCALE_SIZE;         // sin_embedding: the same for coord_mlp.0
 constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + E_SCALE_SIZE + SIN_K * HID;

@@ -355,3 +355,37 @@ def test_pocket_forward_with_other_widths_depths_and_no_time_feature(hidden_nf, 
     out = P.run_hip_forward(dyn, inp, z, t)
     ev, eh = P.report(f'pockets, hidden {hidden_nf}, {inv_sublayers} GCLs per block, time feature {condition_time}', out, ref, z)
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+
+
+# ---- the HBM-resident kernels across magnitudes ------------------------------------------------------------------------------
+@pytest.mark.parametrize('mag', [1e-3, 1e-1, 1e2, 1e4, 1e6, 1e8])
+def test_hbm_resident_kernels_over_twenty_binades_of_magnitude(mag):
+    """Round 5 found the f16x3 edge kernel of the HBM-resident path (pockets, molecules beyond 110 atoms) passing its per-tile
+    activation bound through an int (``readfirstlane`` of the float VALUE): a bound below 1 became 0 - scale 2^60, every
+    activation saturated at the fp16 maximum - and one above 2^31 was clipped; no test had left the range [1, 2^31).  A
+    120-atom molecule whose coordinate model sees ONE dominant feature of magnitude `mag`^2, both arithmetic modes against the oracle
+    (same model on the LDS-resident kernels: a 40-atom molecule)."""
+    from difflinker_amd import Dynamics
+    nf = 9
+    for sizes in ((120, 12), (40, 12)):
+        inp, z, t = P.ragged_inputs(list(sizes), [9, 4], nf, seed=300)
+        special = sizes[0] - 3
+        z[:, :, 3 + 7] = 0.0
+        z[0, special, 3 + 7] = 1.0
+        sd = seeded_state_dict(nf + 2, 128, 1, 301)
+        for v in sd.values():
+            v.zero_()
+        sd['dynamics.embedding.weight'][0, 7] = mag
+        sd['dynamics.e_block_0.gcl_equiv.coord_mlp.0.weight'][0, 0] = mag
+        sd['dynamics.e_block_0.gcl_equiv.coord_mlp.2.weight'][0, 0] = 1e3
+        sd['dynamics.e_block_0.gcl_equiv.coord_mlp.4.weight'][0, 0] = 1.0
+        cfg = EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=1)
+        ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        for precision in ('f16x3', 'fp32'):
+            dyn = Dynamics(n_dims=3, in_node_nf=9, context_node_nf=1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+            dyn.precision = precision
+            dyn.load_state_dict(sd, strict=True)
+            out = P.run_hip_forward(dyn.to(P.dev()), inp, z, t)
+            err = rel_l2(out[0, special, :3], ref[0, special, :3])
+            print(f'{sizes[0]} atoms, magnitude {mag:g}, {precision}: velocity of the atom the feature drives, rel-L2 {err:.2e}')
+            assert err <= 2e-6
