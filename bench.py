@@ -75,7 +75,7 @@ def build_model(cfg, device):
     from difflinker_amd import Dynamics, DynamicsWithPockets, EDM
     torch.manual_seed(0)                                   # random-init weights of the named architecture
     cls = Dynamics if cfg['graph_type'] == 'FC' else DynamicsWithPockets
-    dyn = cls(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128,
+    dyn = cls(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=int(cfg.get('hidden_nf', 128)),
               n_layers=cfg['n_layers'], norm_constant=1e-6, normalization='batch_norm', graph_type=cfg['graph_type'],
               sin_embedding=bool(cfg.get('sin_embedding', False)))
     edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=cfg.get('timesteps', 500), noise_schedule='polynomial_2',
@@ -252,10 +252,11 @@ def secondary_measurements(device, a):
     from difflinker_amd import synthetic
     out = []
 
-    def run(tag, config, batch, precision, note, team='auto', noise=None, sin_embedding=False):
+    def run(tag, config, batch, precision, note, team='auto', noise=None, sin_embedding=False, hidden_nf=128):
         data, cfg = synthetic.make_batch(config, seed=1000, batch=batch)
         cfg['precision'] = precision
         cfg['sin_embedding'] = sin_embedding
+        cfg['hidden_nf'] = hidden_nf                      # (the flop counts below are those of the 128-wide kernels that run it)
         pockets = cfg['graph_type'] != 'FC'
         inp_cpu = synthetic.sampler_inputs(data, pockets=pockets)
         inp = {k: v.to(device) for k, v in inp_cpu.items()}
@@ -299,9 +300,13 @@ def secondary_measurements(device, a):
         'HBM-resident kernels under the host-driven loop', sin_embedding=True)
     run('c2_batch_64_one_cu_each', 'C2', 64, 'f16x3', 'the reference\'s default sampling batch (generate.py:145), one compute unit per '
         'molecule: a quarter of the chip', team=1)
-    for b in (64, 128, 257, 512):
+    for b in (64, 128, 257, 320, 512):
         run(f'c2_batch_{b}', 'C2', b, 'f16x3', 'Dynamics.team = auto: 4 / 2 compute units per molecule while the batch leaves the chip '
-            'room (atoms dealt round-robin, per-atom phases split, sender rows exchanged through HBM once per pass), else one, biggest first')
+            'room (atoms dealt round-robin, per-atom phases split, sender rows exchanged through HBM once per pass), else one, biggest first; '
+            'round 5: up to 1.25x the number of compute units, the molecules beyond one per compute unit are sampled by teams in a second, '
+            'concurrent launch that takes the compute units the smallest molecules leave early (B = 257 was 373..389 molecules/s)')
+    run('c2_hidden_64', 'C2', None, 'f16x3', "the reference's DEFAULT width hidden_nf = 64 (egnn.py:324-329; round 5: narrower networks run "
+        'zero-padded on the 128-wide kernels - the same function at the 128-wide cost; fractions count the 128-wide work)', hidden_nf=64)
     return out
 
 

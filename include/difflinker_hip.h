@@ -81,17 +81,19 @@ typedef enum dl_status {
  *                       unchanged (<= 1e-6; the coordinate model stays F16X3) - inside the 1e-4 bar, outside fp32 class       */
 typedef enum dl_precision { DL_PRECISION_FP32 = 0, DL_PRECISION_F16X3 = 1, DL_PRECISION_F16X2 = 2 } dl_precision;
 
-/* Dynamics.__init__ hyper-parameters (src/egnn.py:324-329).  The HIP path implements the
- * released-config surface (model='egnn_dynamics', SiLU, hidden_nf=128, inv_sublayers=2) plus the optional attention, tanh,
- * aggregation_method='mean' (every kernel family) and sin_embedding (HBM-resident kernels). */
+/* Dynamics.__init__ hyper-parameters (src/egnn.py:324-329).  The HIP path implements model='egnn_dynamics' with SiLU on 128-wide
+ * kernels: the released-config surface plus the optional attention, tanh, aggregation_method='mean' (every kernel family),
+ * sin_embedding (HBM-resident kernels), 1..4 GCLs per block and an optional time feature (ABI v7).  A narrower network
+ * (hidden_nf < 128; the reference's default is 64) is handed over ZERO-PADDED to 128 - the extra hidden features get zero weights
+ * in and out and zero biases (SiLU(0) = 0): exactly the same function; difflinker_amd/egnn.py: pad_to_kernel_width does it. */
 typedef struct dl_config {
     int32_t n_dims;               /* 3                                              */
     int32_t in_node_nf;           /* atom-type channels nf (8 ZINC, 9 GEOM/pockets) */
     int32_t context_node_nf;      /* 1..4                                           */
-    int32_t hidden_nf;            /* must be 128                                    */
+    int32_t hidden_nf;            /* must be 128 (narrower networks: zero-padded, above) */
     int32_t n_layers;             /* EquivariantBlocks (6 GEOM, 8 ZINC)             */
-    int32_t inv_sublayers;        /* must be 2                                      */
-    int32_t condition_time;       /* must be 1                                      */
+    int32_t inv_sublayers;        /* GCLs per EquivariantBlock, 1..4 (2 in every released configuration) */
+    int32_t condition_time;       /* 1: the node inputs are [h, t, context] (released configurations); 0: [h, context] */
     float norm_constant;          /* 1e-6 in the released configs                   */
     float normalization_factor;   /* 100                                            */
     int32_t precision;            /* dl_precision: arithmetic of the 128-wide GEMMs */
@@ -110,7 +112,7 @@ typedef struct dl_config {
 
 typedef struct dl_model dl_model; /* opaque: packed, pre-scaled weights resident in HBM */
 
-/* Number of weight tensors dl_model_create expects: 4 + n_layers * (2*(8 + 2*attention) + 5); with attention every GCL
+/* Number of weight tensors dl_model_create expects: 4 + n_layers * (inv_sublayers*(8 + 2*attention) + 5); with attention every GCL
  * appends att_mlp.0.weight [1,128] and att_mlp.0.bias [1] after its node_mlp tensors. */
 int32_t dl_model_num_tensors(const dl_config* cfg);
 
@@ -119,7 +121,7 @@ int32_t dl_model_num_tensors(const dl_config* cfg);
  * order of the `Dynamics.dynamics` (EGNN) module:
  *   embedding.weight, embedding.bias, embedding_out.weight, embedding_out.bias, then per block i:
  *   gcl_0.edge_mlp.0.{weight,bias}, gcl_0.edge_mlp.2.{weight,bias}, gcl_0.node_mlp.0.{weight,bias},
- *   gcl_0.node_mlp.2.{weight,bias}, (same for gcl_1),
+ *   gcl_0.node_mlp.2.{weight,bias}, (same for gcl_1 .. gcl_{inv_sublayers-1}),
  *   gcl_equiv.coord_mlp.0.{weight,bias}, gcl_equiv.coord_mlp.2.{weight,bias}, gcl_equiv.coord_mlp.4.weight */
 int32_t dl_model_create(const dl_config* cfg, const float* const* weights, int32_t n_tensors, dl_model** out);
 void dl_model_destroy(dl_model* m);

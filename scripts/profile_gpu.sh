@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r02}
 shift || true
-BENCH_ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-secondary}
+BENCH_ARGS=${*:---steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-traffic}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
