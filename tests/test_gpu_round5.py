@@ -389,3 +389,32 @@ def test_hbm_resident_kernels_over_twenty_binades_of_magnitude(mag):
             err = rel_l2(out[0, special, :3], ref[0, special, :3])
             print(f'{sizes[0]} atoms, magnitude {mag:g}, {precision}: velocity of the atom the feature drives, rel-L2 {err:.2e}')
             assert err <= 2e-6
+
+
+def test_trained_like_weights_full_size_chain_against_the_exact_mode():
+    """The benchmark's own launch (config C2, B = 256, T = 500, in-kernel noise) with TRAINED-LIKE weights, once in the default
+    f16x3 arithmetic and once in the exact-fp32 MFMA mode: 501 forwards of accumulated rounding later the two samples still agree
+    on the linker coordinates and in every atom type (the oracle cannot follow at this size: an hour per chain)."""
+    from difflinker_amd import Dynamics, EDM, synthetic
+    data, cfg = synthetic.make_batch('C2', seed=1000)
+    inp = {k: v.to(P.dev()) for k, v in synthetic.sampler_inputs(data).items()}
+    sd = trained_like_state_dict(seeded_state_dict(cfg['nf'] + cfg['ctx'] + 1, 128, cfg['n_layers'], 80, coord_gain=0.02), seed=7)
+    chains = {}
+    for precision in ('f16x3', 'fp32'):
+        dyn = Dynamics(n_dims=3, in_node_nf=cfg['nf'], context_node_nf=cfg['ctx'], hidden_nf=128, n_layers=cfg['n_layers'],
+                       norm_constant=1e-6, normalization='batch_norm')
+        dyn.load_state_dict(sd, strict=True)
+        dyn.precision = precision
+        edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+                  loss_type='l2', norm_values=[1, 4, 10]).to(P.dev())
+        edm.noise_source, edm.noise_seed = 'philox', 5
+        chains[precision] = edm.sample_chain(keep_frames=1, **inp).cpu()
+    lm = inp['linker_mask'].cpu()
+    a, b = chains['f16x3'][0], chains['fp32'][0]
+    ex = rel_l2(a[..., :3] * lm, b[..., :3] * lm)
+    mism = int((a[..., 3:] != b[..., 3:]).any(-1).sum())
+    moved = float(((b[..., :3] - inp['x'].cpu()) * lm).norm(dim=-1).max())
+    print(f'[trained-like weights, C2 B=256 T=500, f16x3 vs fp32 mode] final linker-x rel-L2 {ex:.3e}, atom-type mismatches {mism}, '
+          f'largest linker displacement {moved:.1f} A')
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert ex <= 1e-5 and mism == 0          # measured 3.7e-7, every atom type equal, the largest linker displacement 520 A
