@@ -2165,6 +2165,11 @@ struct Balance {
 void balance_hidden(Balance& b, const double* proxy, int group, bool on) {
     for (int p = 0; p < HID; ++p) { b.perm[p] = p; b.fac[p] = 1.0; }
     if (!on) return;
+    // (a checkpoint with NaN / inf weights must reach the kernels - and FoundNaNException - not an inconsistent sort order: such
+    // features count as the largest)
+    double key[HID];
+    for (int f = 0; f < HID; ++f) key[f] = std::isfinite(proxy[f]) ? proxy[f] : 1.7e308;
+    proxy = key;
     std::stable_sort(b.perm, b.perm + HID, [&](int x, int y) { return proxy[x] > proxy[y]; });
     const double top = proxy[b.perm[0]];
     if (!(top > 0.0) || !std::isfinite(top)) return;

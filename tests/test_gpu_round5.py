@@ -418,3 +418,32 @@ def test_trained_like_weights_full_size_chain_against_the_exact_mode():
           f'largest linker displacement {moved:.1f} A')
     assert torch.isfinite(a).all() and torch.isfinite(b).all()
     assert ex <= 1e-5 and mism == 0          # measured 3.7e-7, every atom type equal, the largest linker displacement 520 A
+
+
+@pytest.mark.parametrize('bad', [float('nan'), float('inf')])
+def test_non_finite_weights_reach_the_kernels_and_raise(bad):
+    """The balanced packing sorts hidden features by a magnitude proxy on the host: a checkpoint with a NaN / inf weight must not
+    upset that sort (or anything else there) - it has to reach the kernels and come back as FoundNaNException, like the reference."""
+    from difflinker_amd.utils import FoundNaNException
+    nf = 9
+    dyn, sd, cfg = P.make_dynamics(nf, 1, 2, seed=77)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd['dynamics.e_block_0.gcl_1.edge_mlp.0.weight'][5, 17] = bad
+    sd['dynamics.e_block_1.gcl_0.node_mlp.0.weight'][40, 200] = bad
+    dyn.load_state_dict(sd, strict=True)
+    dyn.invalidate_packed()
+    inp, z, t = P.ragged_inputs([30, 12], [5, 3], nf, seed=78)
+    try:
+        egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        oracle_raised = False
+    except egnn_oracle.OracleNaN:
+        oracle_raised = True
+    assert oracle_raised or bad == float('inf')          # (an inf weight may give inf, not NaN: the reference checks isnan only)
+    if oracle_raised:
+        with pytest.raises(FoundNaNException):
+            P.run_hip_forward(dyn, inp, z, t)
+    else:
+        try:
+            P.run_hip_forward(dyn, inp, z, t)             # must not crash; f16x3 beyond its range answers FoundNaNException (documented)
+        except FoundNaNException:
+            pass
