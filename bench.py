@@ -200,7 +200,9 @@ def measure_traffic(a, cfg, child_T=50):
                '--traffic-child', '--config', a.config, '--T', str(child_T), '--noise', a.noise, '--steps', '1', '--warmup', '1',
                '--no-secondary', '--no-cpu-baseline'] + (['--batch', str(a.batch)] if a.batch is not None else []) + \
               (['--precision', a.precision] if a.precision else []) + (['--uniform-size'] if a.uniform_size else [])
-        env = dict(os.environ, TMPDIR='/tmp')
+        # (counter collection of ROCm 7.2 crashes on cooperative launches - the second launch of a split chain is one: the child
+        # issues the same kernel, grid and arguments through the plain launch API)
+        env = dict(os.environ, TMPDIR='/tmp', DIFFLINKER_TEAM_LAUNCH_PLAIN='1')
         try:
             subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
             vals = []
@@ -210,7 +212,8 @@ def measure_traffic(a, cfg, child_T=50):
                         vals.append(float(r['Counter_Value']))
             if not vals:
                 return None, f'not measured: the {counter} pass recorded no launch of sample_chain_fc_kernel'
-            per_forward[counter] = sum(vals) / len(vals) * 1024.0 / (child_T + 1)
+            # the child samples 2 chains (1 warm-up + 1); a chain may be two launches (EDM.split_chain): per chain, not per launch
+            per_forward[counter] = sum(vals) / 2.0 * 1024.0 / (child_T + 1)
         except Exception as e:
             return None, f'not measured: the rocprofv3 --pmc {counter} pass failed ({type(e).__name__})'
         finally:
@@ -433,6 +436,7 @@ def main():
     for _ in range(a.steps):
         one_chain()
         kernel_ms.append(getattr(edm, 'last_kernel_events', None))
+        split_events = getattr(edm, 'last_split_event', None)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -495,7 +499,10 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': executed / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
                          'frac_of_fp32_vector_peak': executed / FP32_MFMA_PEAK_TFLOPS,
-                         'kernel': 'sample_chain_fc_kernel' if not pockets else 'all kernels of the chain (pk_edge_kernel dominates)', 'kernel_ms': k_avg_ms,
+                         'kernel': ('sample_chain_fc_kernel' + (' - two launches per chain (EDM.split_chain: <1,false,false> for every molecule, then '
+                                                               '<1,true,false> for the big ones on teams of two; kernel_ms = both, see split_chain)'
+                                                               if getattr(edm, 'split_chain', False) and split_events is not None else ''))
+                         if not pockets else 'all kernels of the chain (pk_edge_kernel dominates)', 'kernel_ms': k_avg_ms,
                          'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1),
                          'counts': 'executed work: GCL edge models on every pair, coordinate edge model on the ' + str(pairs_coord) + ' of '
                                    + str(pairs) + ' pairs per pass whose receiving atom is inside the linker mask, per-atom GEMMs',
@@ -504,6 +511,8 @@ def main():
                                                  'of a block / the same kernel time'},
                          # kept for continuity with rounds 1-2, whose lines carried the executed figures under this key
                          'executed': {'achieved': executed, 'frac': executed / peak, 'flops_per_launch': flops_fwd_exec * (cfg['T'] + 1)}},
+            'split_chain': None if not getattr(edm, 'split_chain', False) or split_events is None or kernel_ms[0] is None else
+                {'first_launch_ms': kernel_ms[-1][0].elapsed_time(split_events), 'second_phase_ms': split_events.elapsed_time(kernel_ms[-1][1])},
             'per_rank': per_rank,
             'per_rank_note': None if per_rank is None else
                 'all_gather_ms is measured on each rank from the moment ITS chain is enqueued-complete to the end of the collective: it '

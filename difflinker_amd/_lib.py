@@ -62,6 +62,7 @@ class DLChainArgs(ctypes.Structure):
         ('chain', ctypes.c_void_p), ('nan_flags', ctypes.c_void_p), ('nan_step', ctypes.c_void_p),
         ('order', ctypes.c_void_p), ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
         ('mol_index', ctypes.c_void_p), ('order_first', ctypes.c_int32), ('order_count', ctypes.c_int32),
+        ('q_begin', ctypes.c_void_p), ('q_end', ctypes.c_void_p), ('z_state', ctypes.c_void_p), ('skip_flags', ctypes.c_void_p),
     ]
 
 

@@ -1846,7 +1846,7 @@ template <int PREC, bool TEAM, bool ATT>
 __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     __shared__ __attribute__((aligned(16))) float lds_raw[L_TOTAL];   // static: every LDS address is a constant
     const Lds v = lds_view(lds_raw);
-    int T;
+    int T, qb, qe;
     {
         const dl_chain_args& g = p.a;
         const int tid = threadIdx.x;
@@ -1861,6 +1861,10 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         const int N = g.N, nf = p.md.nf, D = 3 + nf, K = g.keep_frames, B = g.B;
         const int limit = TEAM ? NQMAX : NMAX;
         T = g.T;
+        // a chain in two launches (dl_chain_args.q_begin / q_end): this launch's part of the T + 1 denoiser calls of molecule b
+        qb = g.q_begin ? g.q_begin[b] : 0;
+        qe = g.q_end ? g.q_end[b] : T + 1;
+        if (g.skip_flags && g.skip_flags[b] != 0) return;          // (it ended in the first launch; every member takes this branch)
         const int8_t* nm = g.node_mask + size_t(b) * N;
         const size_t frame = size_t(B) * N * D;
         float* chain_b = g.chain + size_t(b) * N * D;
@@ -1902,13 +1906,27 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
             else { val = __fdiv_rn(__fsub_rn(g.h[n * nf + d - 3], g.bias_h), g.norm_h); eps0 = philox ? 0.0f : g.noise_h[n * nf + d - 3]; }
             if (philox) eps0 = philox_normal(g.noise_seed, gmol, unsigned(pos), 0u, unsigned(d));
             const float lm = v.lm[l];
-            v.z[l * DMAX + d] = __fadd_rn(__fmul_rn(val, v.frag[l]), __fmul_rn(__fmul_rn(eps0, lm), lm));
+            float z0 = __fadd_rn(__fmul_rn(val, v.frag[l]), __fmul_rn(__fmul_rn(eps0, lm), lm));
+            if (qb > 0) z0 = g.z_state[n * D + d];                 // resumed: the state the first launch left
+            v.z[l * DMAX + d] = z0;
         }
         __syncthreads();
     }
 #pragma nounroll
-    for (int q = 0; q <= T; ++q)
+    for (int q = qb; q < qe; ++q)
         if (!chain_step2<PREC, TEAM, ATT>(v, q)) return;
+    if (qe <= T) {                                                 // stopped early: hand the state over (dl_chain_args.z_state)
+        const auto* P = kargs<ChainArgs>();
+        const int tid = lane_ids().tid;
+        const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), D = 3 + P->md.nf, N = P->a.N;
+        const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+        const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
+        for (int e = tid; e < nown * D; e += THREADS) {
+            const int l = e / D, d = e - l * D;
+            P->a.z_state[(size_t(b) * N + v.idx[rank + l * S]) * D + d] = v.z[l * DMAX + d];
+        }
+        return;
+    }
     {   // frame 0: the final sample [x, one_hot(h)] of the own atoms
         const auto* P = kargs<ChainArgs>();
         const int tid = lane_ids().tid;
@@ -2521,8 +2539,13 @@ static int32_t fc_workspace(int32_t B, int32_t team, void* ws, size_t ws_bytes, 
 // checks the grid against the occupancy of the kernel on this device and fails (hipErrorCooperativeLaunchTooLarge) instead of
 // starting a launch that could not assemble; what it cannot see - another stream or process holding compute units - ends in
 // the bounded wait of team_sync and flag bit 3.
+// (DIFFLINKER_TEAM_LAUNCH_PLAIN=1: the same kernel, grid and arguments through hipLaunchKernel - for counter collection only:
+// rocprofv3 --pmc of ROCm 7.2 dies with a segmentation fault on a cooperative launch (profiles/r05/README.md); the grid has been
+// checked against dl_team_max() either way)
 static hipError_t launch_team(const void* kernel, int grid, hipStream_t st, void* args) {
     void* params[] = {args};
+    static const bool plain = [] { const char* e = getenv("DIFFLINKER_TEAM_LAUNCH_PLAIN"); return e && e[0] == '1'; }();
+    if (plain) return hipLaunchKernel(kernel, dim3(grid), dim3(THREADS), params, 0, st);
     return hipLaunchCooperativeKernel(kernel, dim3(grid), dim3(THREADS), params, 0, st);
 }
 
@@ -2578,6 +2601,7 @@ int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* g, void* stre
     if (g->B < 0 || g->N < 1 || g->T < 1 || g->keep_frames < 1 || g->keep_frames > g->T || g->team < 0) return DL_ERR_BAD_ARG;
     if (g->order_first < 0 || g->order_count < 0 || g->order_first + g->order_count > g->B) return DL_ERR_BAD_ARG;
     if ((g->order_first != 0 || g->order_count != 0) && !g->order) return DL_ERR_BAD_ARG;
+    if ((g->q_begin || g->q_end) && !g->z_state) return DL_ERR_BAD_ARG;
     if (m->cfg.sin_embedding) return DL_ERR_UNSUPPORTED;       // (host-driven loop over dl_egnn_forward_fc_large instead)
     if (g->B == 0) return DL_OK;
     const int32_t count = g->order_count > 0 ? g->order_count : g->B;        // molecules of this launch

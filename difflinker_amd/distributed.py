@@ -5,7 +5,10 @@ process group's backend is ``nccl``; ``gloo`` in the CPU tests).
 
 One process per GPU (``torch.distributed``); rank r takes a contiguous slice of the collated
 batch.  Noise comes from the in-kernel counter-based generator keyed by the GLOBAL molecule index
-(or from an explicit global bank, sliced), so the sample of molecule b does not depend on the world size.
+(or from an explicit global bank, sliced), so the sample of molecule b does not depend on the world size - bit for bit with one
+launch per chain (``edm.split_chain = False``, ``edm.overflow_teams = False``); with the default two-launch chain of a ragged
+shard that fills its GPU (``EDM.split_chain``: the big molecules finish on teams of two, whose summation order differs) to fp32
+rounding, ~1e-8 on the final coordinates.
 """
 import time
 

@@ -19,6 +19,7 @@ Out of scope (training only): ``EDM.forward`` and the likelihood/KL terms (edm.p
 ``GammaNetwork`` schedule.
 """
 import ctypes
+import os
 import warnings
 
 import numpy as np
@@ -28,6 +29,86 @@ import torch.nn.functional as F
 from . import _lib, utils
 from .egnn import Dynamics, DynamicsWithPockets
 from .noise import PredefinedNoiseSchedule
+
+
+# measured +2.8 .. 3.2 % on the C2 headline, same box (profiles/r05/ab_split_chain.log); DIFFLINKER_SPLIT_CHAIN=0 turns it off
+SPLIT_CHAIN_DEFAULT = os.environ.get('DIFFLINKER_SPLIT_CHAIN', '1') == '1'
+
+
+def cus_or_none(dev):
+    return torch.cuda.get_device_properties(dev).multi_processor_count
+
+
+def _pass_steps(receivers, senders):
+    """pair-loop steps of one pass (egnn_fc.hip: slot_plan): `receivers` atoms share 256 slots, a slot walks ceil(senders / g) senders"""
+    if receivers <= 0:
+        return 0
+    g = max(1, min(256 // receivers, senders))
+    return -(-senders // g)
+
+
+def forward_cost(n, n_linker, n_layers, sublayers, team=1):
+    """Relative cost of one denoiser call for a molecule of `n` atoms (`n_linker` of them receivers of the coordinate pass) on
+    `team` compute units, in units of one pair-loop step: steps of the GCL and coordinate passes plus a per-pass overhead fitted
+    to the measured forward times (profiles/r04/forward_time_vs_n.log: 0.68 / 0.86 / 1.02 / 1.14 ms at n = 35 / 40 / 43 / 50 on one
+    compute unit, 0.68 ms at n = 50 on a team of two).  Only the RATIOS matter: they place the hand-over step of split_plan."""
+    own, own_l = -(-n // team), -(-max(n_linker, 1) // team)
+    a_gcl, a_eq = (1.6, 1.1) if team == 1 else (1.7, 1.3)
+    return n_layers * (sublayers * (_pass_steps(own, n) + a_gcl) + _pass_steps(own_l, n) + a_eq)
+
+
+_PLAN_CACHE = {}
+
+
+def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_gain=0.02, grid=48, allow_singles=None):
+    """The static hand-over inside a ragged batch that holds one compute unit per molecule.  FIRST launch: every molecule on its
+    compute unit for about the same time tau - the small molecules complete their chain, every other molecule b stops after
+    s_b = floor(tau / cost_b) denoiser calls and leaves its state in HBM.  SECOND phase: the unfinished molecules finish on TEAMS
+    OF TWO, which take the compute units the small ones left (2 x teams <= compute units).  tau runs over a grid between the
+    cheapest and the dearest molecule's chain; the plan with the smallest predicted makespan wins, provided it beats the single
+    launch by `min_gain`.  A function of the sizes alone (cached by them).
+    ``allow_singles`` (measured, not adopted: profiles/r05/ab_split_chain.log): when the compute units do not suffice for teams
+    everywhere, the molecules with the least work left resume on ONE compute unit each in a launch beside the teams' - a better
+    makespan on paper (0.90 instead of 0.94 of the single launch at C2), a worse one on the chip, whose power cap taxes a first
+    launch that keeps every compute unit busy to its end.
+    Returns (q_end of the first launch [B], molecules for teams, molecules for single compute units) or None."""
+    B = len(sizes)
+    if B > compute_units or B == 0:
+        return None
+    allow_singles = bool(allow_singles)
+    key = (tuple(sizes), tuple(linkers), n_calls, compute_units, n_layers, sublayers, min_gain, grid, bool(allow_singles))
+    if key in _PLAN_CACHE:
+        return _PLAN_CACHE[key]
+    table = {}
+    for n, l in set(zip(sizes, linkers)):
+        table[(n, l)] = (forward_cost(n, l, n_layers, sublayers, 1), forward_cost(n, l, n_layers, sublayers, 2))
+    c1 = np.array([table[k][0] for k in zip(sizes, linkers)])
+    c2 = np.array([table[k][1] for k in zip(sizes, linkers)])
+    single = float(c1.max()) * n_calls
+    lo = float(c1.min()) * n_calls
+    best = None
+    for i in range(1, grid):
+        tau = lo + (single - lo) * i / grid
+        q_end = np.clip((tau / c1).astype(np.int64), 1, n_calls)
+        rest = np.nonzero(q_end < n_calls)[0]
+        if rest.size == 0:
+            continue
+        left1 = (n_calls - q_end[rest]) * c1[rest]
+        rest = rest[np.lexsort((rest, -left1))]                     # most work left first; ties by index: deterministic
+        m = min(rest.size, compute_units - rest.size)               # teams of two: 2 m + (unfinished - m) <= compute units
+        if m < 0 or (m < rest.size and not allow_singles):
+            continue
+        teams, singles = rest[:m], rest[m:]
+        second = max(float(((n_calls - q_end[teams]) * c2[teams]).max()) if m else 0.0,
+                     float(((n_calls - q_end[singles]) * c1[singles]).max()) if singles.size else 0.0)
+        total = float((q_end * c1).max()) + second
+        if best is None or total < best[0]:
+            best = (total, q_end.tolist(), teams.tolist(), singles.tolist())
+    plan = None if best is None or best[0] > (1.0 - min_gain) * single else (best[1], best[2], best[3])
+    if len(_PLAN_CACHE) > 64:
+        _PLAN_CACHE.clear()
+    _PLAN_CACHE[key] = plan
+    return plan
 
 
 # second stream (and its workspace) of the launch that samples the molecules beyond one per compute unit on teams
@@ -78,6 +159,13 @@ class EDM(torch.nn.Module):
         # second, concurrent launch (see _sample_chain_fused) instead of waiting for a second round.  Their messages are then
         # summed in the team's order: False keeps every molecule on one compute unit (bitwise the numbers of any other split).
         self.overflow_teams = True
+        # a ragged batch that fills the chip (one molecule per compute unit): the chain runs in TWO launches - every molecule on its
+        # compute unit until the small ones are done, then the big ones finish on teams of two that take the freed compute units
+        # (see _sample_chain_fused / split_plan).  The steps a molecule runs on a team are summed in the team's order (fp32
+        # rounding); the plan is a function of the batch's sizes alone, so a batch is sampled bit for bit the same every time.
+        # False: one launch, every molecule on one compute unit for the whole chain.
+        self.split_chain = SPLIT_CHAIN_DEFAULT
+        self.split_singles = os.environ.get('DIFFLINKER_SPLIT_SINGLES', '0') == '1'     # (measured, not adopted: see split_plan)
 
     @staticmethod
     def _side_stream(dev):
@@ -437,8 +525,22 @@ class EDM(torch.nn.Module):
                               f'the rest) use the chip evenly', RuntimeWarning, stacklevel=3)
         ws, ws_bytes = self.dynamics.workspace(bs - over, team, dev)
 
-        def chain_args(flags_, steps_, team_, ws_, ws_bytes_, first, count):
+        # the static hand-over inside a ragged batch that fills the chip (split_plan): two launches
+        plan = None
+        if team == 1 and over == 0 and self.split_chain and not self.dynamics._no_teams and bs <= cus_or_none(dev) and T >= 20:
+            sizes_h = nm.ne(0).sum(1).cpu().tolist()
+            if max(sizes_h) <= int(lib.dl_max_atoms()) and min(sizes_h) > 0:
+                plan = split_plan(sizes_h, lm.ne(0).sum(1).cpu().tolist(), T + 1, cus_or_none(dev), self.dynamics.n_layers,
+                                  int(getattr(self.dynamics, 'inv_sublayers', 2)), allow_singles=bool(self.split_singles))
+        q_end_t = z_state = None
+        if plan is not None:
+            q_end_t = torch.tensor(plan[0], dtype=torch.int32, device=dev)
+            z_state = torch.empty((bs, n, self.n_dims + nf), device=dev)
+
+        def chain_args(flags_, steps_, team_, ws_, ws_bytes_, first, count, q_begin=None, q_end=None, skip=None, order_=None):
             return _lib.DLChainArgs(
+                q_begin=q_begin.data_ptr() if q_begin is not None else None, q_end=q_end.data_ptr() if q_end is not None else None,
+                z_state=z_state.data_ptr() if z_state is not None else None, skip_flags=skip.data_ptr() if skip is not None else None,
                 B=bs, N=n, T=T, keep_frames=keep_frames,
                 x=xs.data_ptr(), h=hs.data_ptr(), node_mask=nm.data_ptr(), fragment_mask=fm.data_ptr(),
                 linker_mask=lm.data_ptr(), edge_mask=em.data_ptr() if em is not None else None,
@@ -447,10 +549,11 @@ class EDM(torch.nn.Module):
                 noise_seed=seed, mol_offset=int(mol_offset), team=team_, coefs=coefs.data_ptr(),
                 inv_alpha0=inv_alpha0, sigma0=sigma0, sigma_x=sigma_x,
                 norm_x=float(self.norm_values[0]), norm_h=float(self.norm_values[1]), bias_h=float(self.norm_biases[1]),
-                chain=chain.data_ptr(), nan_flags=flags_.data_ptr(), nan_step=steps_.data_ptr(), order=order.data_ptr(),
+                chain=chain.data_ptr(), nan_flags=flags_.data_ptr(), nan_step=steps_.data_ptr(),
+                order=(order if order_ is None else order_).data_ptr(),
                 workspace=ws_.data_ptr(), workspace_bytes=ws_bytes_,
                 mol_index=mol_index.data_ptr() if mol_index is not None else None, order_first=first, order_count=count)
-        args = chain_args(flags, steps, team, ws, ws_bytes, 0, bs - over if over else 0)
+        args = chain_args(flags, steps, team, ws, ws_bytes, 0, bs - over if over else 0, q_end=q_end_t)
         with torch.cuda.device(dev):
             cur = torch.cuda.current_stream(dev)
             if getattr(self, 'profile_events', False):     # bench.py: HIP events right around the launch
@@ -483,6 +586,52 @@ class EDM(torch.nn.Module):
                         t_.record_stream(side)             # the caching allocator must not hand these out while the side launch runs
                 flags = flags | flags2
                 steps = torch.where(steps2 >= 0, steps2, steps)
+            if plan is not None:
+                # second phase: the molecules with the most work left resume from z_state on teams of two (a launch on the side stream),
+                # the others on one compute unit each (a launch on this stream) - side by side, both behind the first launch; a
+                # molecule that ended in the first launch (NaN) is skipped
+                by_size = lambda idx: torch.tensor(sorted(idx, key=lambda b_: (-sizes_h[b_], b_)), dtype=torch.int32, device=dev)  # noqa: E731
+                after_first = torch.cuda.Event(enable_timing=bool(getattr(self, 'profile_events', False)))
+                after_first.record(cur)
+                self.last_split_event = after_first
+                parts = []
+                if plan[1]:
+                    side = self._side_stream(dev)
+                    rest, m2 = by_size(plan[1]), len(plan[1])
+                    flags2 = torch.zeros(bs, dtype=torch.int32, device=dev)
+                    steps2 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+                    need2 = int(lib.dl_workspace_bytes(m2, 2))
+                    ws2 = _SIDE_WORKSPACE.get(side)
+                    if ws2 is None or ws2.numel() < need2:
+                        ws2 = _SIDE_WORKSPACE[side] = torch.empty(need2, dtype=torch.uint8, device=dev)
+                    args2 = chain_args(flags2, steps2, 2, ws2, need2, 0, m2, q_begin=q_end_t, skip=flags, order_=rest)
+                    side.wait_event(after_first)
+                    _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args2), ctypes.c_void_p(side.cuda_stream)),
+                               'dl_sample_chain_fc (second phase of a split chain: teams of two)')
+                    done2 = torch.cuda.Event()
+                    done2.record(side)
+                    parts.append((flags2, steps2, done2, rest))
+                if plan[2]:
+                    rest1, m1 = by_size(plan[2]), len(plan[2])
+                    flags3 = torch.zeros(bs, dtype=torch.int32, device=dev)
+                    steps3 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+                    need3 = int(lib.dl_workspace_bytes(m1, 1))
+                    ws3 = _SIDE_WORKSPACE.get(cur)
+                    if ws3 is None or ws3.numel() < need3:
+                        ws3 = _SIDE_WORKSPACE[cur] = torch.empty(need3, dtype=torch.uint8, device=dev)
+                    args3 = chain_args(flags3, steps3, 1, ws3, need3, 0, m1, q_begin=q_end_t, skip=flags, order_=rest1)
+                    _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args3), ctypes.c_void_p(cur.cuda_stream)),
+                               'dl_sample_chain_fc (second phase of a split chain: one compute unit each)')
+                    parts.append((flags3, steps3, None, rest1))
+                for f_, s_, done_, rest_ in parts:
+                    if done_ is not None:
+                        cur.wait_event(done_)
+                        for t_ in (xs, hs, nm, fm, lm, em, ctx, coefs, rest_, chain, noise_x, noise_h, mol_index, q_end_t, z_state, flags):
+                            if t_ is not None:
+                                t_.record_stream(side)
+                    # (the single-compute-unit kernel initialises its molecules' words itself: 0 / -1; merge only what the phase set)
+                    flags = flags | f_
+                    steps = torch.where(s_ >= 0, s_, steps)
             if getattr(self, 'profile_events', False):
                 ev1.record(cur)
                 self.last_kernel_events = (ev0, ev1)

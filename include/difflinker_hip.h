@@ -236,6 +236,18 @@ typedef struct dl_chain_args {
                                  * caller put the few molecules beyond one-per-compute-unit on TEAMS in a second launch on another
                                  * stream - they take the compute units the smallest molecules of the first launch leave early -
                                  * instead of waiting for a whole second round (EDM.sample_chain, batches of 257..320 on 256 CUs) */
+    /* (ABI v7) a chain in TWO launches - the static hand-over of compute units inside a ragged batch: molecule b runs the denoiser
+     * calls q_begin[b] .. q_end[b]-1 of the T+1 (NULL: 0 / T+1).  A launch that stops a molecule early (q_end[b] <= T) writes its
+     * state z (normalised, fp32, exactly as the kernel holds it) to z_state[b]; a launch that resumes one (q_begin[b] > 0) starts
+     * from there instead of from x, h and draw 0.  The noise is a function of (molecule, atom, draw) - resuming needs no generator
+     * state; frames are written by step index, frame 0 by the launch that runs the decode.  skip_flags (NULL or device [B]): a
+     * molecule with a non-zero word is left alone (it ended - NaN - in the first launch).  EDM.sample_chain: the small molecules
+     * of a batch finish in the first launch, the big ones stop where the small ones end and finish on TEAMS OF TWO in the second,
+     * which uses the compute units the small ones left. */
+    const int32_t* q_begin;
+    const int32_t* q_end;
+    float* z_state;             /* device [B,N,3+nf]; required when q_begin or q_end is given */
+    const int32_t* skip_flags;
 } dl_chain_args;
 
 int32_t dl_sample_chain_fc(const dl_model* m, const dl_chain_args* args, void* stream);

@@ -26,6 +26,9 @@ run() {  # name, rocprof args...
   rm -rf /tmp/rp_$name
 }
 run trace --kernel-trace --stats
+# counter collection (rocprofv3 --pmc, ROCm 7.2) dies with a segmentation fault on hipLaunchCooperativeKernel - the second launch of a
+# split chain, every team launch: the same kernel, grid and arguments through the plain launch API for these passes
+export DIFFLINKER_TEAM_LAUNCH_PLAIN=1
 run pmc_mfma --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE

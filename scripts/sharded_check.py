@@ -37,6 +37,7 @@ edm = EDM(dyn, in_node_nf=cfg['nf'], n_dims=3, timesteps=500, noise_schedule='po
 edm.T = a.T
 edm.noise_source = 'philox'
 edm.noise_seed = 11
+edm.split_chain = edm.overflow_teams = False       # one launch per chain: the setting under which a sample is BITWISE independent of the split
 got = sample_chain_sharded(edm, inp, keep_frames=2)
 torch.cuda.synchronize()
 if world == 1:

@@ -21,7 +21,11 @@ with open(os.path.join(dst, f'kernel_stats_{tag}.csv'), 'w', newline='') as f:
     for r in rows:
         r[0] = r[0] if len(r[0]) < 140 else r[0][:100] + ' ... ' + r[0][-30:]
         w.writerow(r)
-avg_ns = next(float(r[3]) for r in rows[1:] if kernel in r[0])
+# a chain may be TWO launches (EDM.split_chain: <.., false, ..> for every molecule, then <.., true, ..> for the big ones on teams):
+# per-chain figures = totals over both kernels / number of chains (= launches of the kernel with the largest total)
+match = [r for r in rows[1:] if kernel in r[0]]
+chains = int(max(match, key=lambda r: float(r[2]))[1])
+avg_ns = sum(float(r[2]) for r in match) / chains
 
 sums, counts, meta = {}, {}, {}
 for path in glob.glob(os.path.join(src, 'pmc_*_counter_collection.csv')):
@@ -32,9 +36,9 @@ for path in glob.glob(os.path.join(src, 'pmc_*_counter_collection.csv')):
         counts[r['Counter_Name']] = counts.get(r['Counter_Name'], 0) + 1
         meta = {k: r[k] for k in ('Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'Scratch_Size', 'VGPR_Count',
                                   'Accum_VGPR_Count', 'SGPR_Count')}
-out = {k: sums[k] / counts[k] for k in sorted(sums)}
+out = {k: sums[k] / chains for k in sorted(sums)}       # per chain (see above)
 out['_kernel_meta'] = meta
-d = {'kernel_avg_ms_rocprof': avg_ns / 1e6, 'forwards_per_launch': forwards}
+d = {'kernel_avg_ms_rocprof': avg_ns / 1e6, 'forwards_per_launch': forwards, 'launches_per_chain': {r[0][:90]: int(r[1]) / chains for r in match}}
 if 'GRBM_GUI_ACTIVE' in out:
     d['gui_active_per_xcd_cycles'] = out['GRBM_GUI_ACTIVE'] / 8
     d['effective_clock_GHz'] = d['gui_active_per_xcd_cycles'] / avg_ns

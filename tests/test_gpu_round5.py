@@ -447,3 +447,65 @@ def test_non_finite_weights_reach_the_kernels_and_raise(bad):
             P.run_hip_forward(dyn, inp, z, t)             # must not crash; f16x3 beyond its range answers FoundNaNException (documented)
         except FoundNaNException:
             pass
+
+
+# ---- a chain in two phases: the static hand-over --------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['teams only', 'teams and single compute units'])
+def test_split_chain_hands_compute_units_over_and_samples_the_oracles_chain(case):
+    """``EDM.split_chain``: the small molecules of a ragged batch complete in the first launch, the others stop at the call where
+    the small ones end (dl_chain_args.q_end), leave their state in HBM and finish in a second phase (q_begin, z_state) - the ones
+    with the most work left on teams of two, and, when the compute units do not suffice for teams everywhere (the second case:
+    more unfinished molecules than half the compute units - the shape of the C2 plan: 124 teams + 8 singles), the rest on one compute
+    unit each, side by side (here 136 unfinished: 120 teams + 16 singles).  The chain must be the oracle's - every kept frame - and agree with the one-launch chain to fp32
+    rounding (the steps on teams sum messages in the team's order); molecules that never run on a team are bit-identical;
+    repeatable bit for bit; the plan comes from the sizes alone."""
+    from difflinker_amd import edm as edm_mod
+    nf, L, T = 8, (2 if case == 'teams only' else 1), 24
+    if case == 'teams only':
+        sizes, linkers = [50, 48, 50, 47, 20, 22, 18, 25, 21, 19, 23, 20], [8, 7, 9, 6, 4, 5, 3, 6, 4, 4, 5, 4]
+    else:
+        sizes, linkers = [30] * 100 + [26] * 36 + [10] * 60, [6] * 100 + [5] * 36 + [3] * 60          # 136 unfinished: 120 teams + 16 singles
+    cus = torch.cuda.get_device_properties(P.dev()).multi_processor_count
+    plan = edm_mod.split_plan(sizes, linkers, T + 1, cus, L, 2, allow_singles=(case != 'teams only'))
+    assert plan is not None
+    q_end, teams, singles = plan
+    assert teams and all(0 < q_end[b] < T + 1 for b in teams + singles) and 2 * len(teams) + len(singles) <= cus
+    assert (len(singles) > 0) == (case != 'teams only')
+    untouched = sorted(set(range(len(sizes))) - set(teams))              # complete in the first launch, or resume on ONE compute unit
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=171)
+    dyn.team = 1
+    inp, _, _ = P.ragged_inputs(sizes, linkers, nf, seed=172)
+    B, N = inp['x'].shape[:2]
+    edm = _edm(dyn, nf, T)
+    edm.split_singles = case != 'teams only'        # (the variant with single compute units beside the teams is opt-in: split_plan)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=173)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'], inp['edge_mask'],
+                            inp['context'], bank, keep_frames=6)
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+
+    def run(split, philox=False):
+        edm.split_chain = split
+        if philox:
+            edm.noise_source, edm.noise_seed = 'philox', 9
+            out = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                                   keep_frames=6)
+            edm.noise_source = 'torch'
+        else:
+            out = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                                   keep_frames=6, noise_bank=bank.stacked())
+        torch.cuda.synchronize()
+        return out.cpu()
+    got = run(True)
+    P.check_chain(f'split chain ({case}: {len(teams)} teams, {len(singles)} singles), T=24, 6 frames', got, want, inp)
+    assert torch.equal(got, run(True)), 'bitwise repeatable'
+    one = run(False)
+    assert torch.equal(got[:, untouched], one[:, untouched]), 'molecules that never run on a team: the bits of the one-launch chain'
+    lm = inp['linker_mask'][teams]
+    err = rel_l2(got[0, teams, :, :3] * lm, one[0, teams, :, :3] * lm)
+    print(f'split vs one launch, the molecules that finish on teams: linker-x rel-L2 {err:.3e}')
+    assert err <= 1e-5 and torch.equal(got[0, teams, :, 3:], one[0, teams, :, 3:])
+    a, b = run(True, philox=True), run(False, philox=True)                       # in-kernel noise: resuming needs no generator state
+    assert rel_l2(a[0, :, :, :3] * inp['linker_mask'], b[0, :, :, :3] * inp['linker_mask']) <= 1e-5
+    assert torch.equal(a[:, untouched], b[:, untouched])

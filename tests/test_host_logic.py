@@ -39,7 +39,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.dl_workspace_bytes(8, 0) == lib.dl_workspace_bytes(8, 1) == 8 * w1
     assert lib.dl_workspace_bytes(8, 4) > 4 * lib.dl_workspace_bytes(8, 1) and lib.dl_workspace_bytes(8, 3) >= 0
     assert lib.dl_team_max(64) in (1, 2, 4, 8) and lib.dl_team_max(0) == 1         # 1 without a device (a query, not a compute call)
-    assert ctypes.sizeof(_lib.DLChainArgs) == 200                                   # dl_chain_args of ABI v7 (LP64): v6's 192 + order_first, order_count
+    assert ctypes.sizeof(_lib.DLChainArgs) == 232                                   # dl_chain_args of ABI v7 (LP64): v6's 192 + order_first, order_count + q_begin, q_end, z_state, skip_flags
     assert lib.dl_max_atoms() == 55
     assert lib.dl_error_string(-2).decode().startswith('hyper-parameter')
     cfg = _lib.DLConfig(3, 9, 1, 128, 6, 2, 1, 1e-6, 100.0, 1)
