@@ -509,3 +509,36 @@ def test_split_chain_hands_compute_units_over_and_samples_the_oracles_chain(case
     a, b = run(True, philox=True), run(False, philox=True)                       # in-kernel noise: resuming needs no generator state
     assert rel_l2(a[0, :, :, :3] * inp['linker_mask'], b[0, :, :, :3] * inp['linker_mask']) <= 1e-5
     assert torch.equal(a[:, untouched], b[:, untouched])
+
+
+def test_split_chain_reports_nans_of_either_launch_like_one_launch():
+    """A NaN in a molecule that stops in the first launch of a split chain and resumes in the second: planted in a draw of the
+    FIRST launch it ends the molecule there (the second launch skips it: dl_chain_args.skip_flags); planted in a draw of the
+    SECOND launch it is found on the team.  Either way the exception carries what the one-launch chain reports: the same index
+    sets and the same denoiser call."""
+    from difflinker_amd import edm as edm_mod
+    from difflinker_amd.utils import FoundNaNException
+    nf, L, T = 8, 1, 24
+    sizes, linkers = [50, 48, 50, 47, 20, 22, 18, 25, 21, 19, 23, 20], [8, 7, 9, 6, 4, 5, 3, 6, 4, 4, 5, 4]
+    q_end, teams, _ = edm_mod.split_plan(sizes, linkers, T + 1, 256, L, 2)
+    assert 0 in teams and 2 in teams and 3 < q_end[0] < T - 3
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=181)
+    dyn.team = 1
+    inp, _, _ = P.ragged_inputs(sizes, linkers, nf, seed=182)
+    B, N = inp['x'].shape[:2]
+    edm = _edm(dyn, nf, T)
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=183)
+    for draw, mol in ((2, 0), (q_end[2] + 2, 2)):                   # a draw of the first launch / of the second
+        nx, nh = (t_.clone() for t_ in bank.stacked())
+        nx[draw, mol, sizes[mol] - 1, 0] = float('nan')            # a linker atom: z after step draw - 1 holds a NaN -> call `draw`
+        seen = {}
+        for split in (False, True):
+            edm.split_chain = split
+            with pytest.raises(FoundNaNException) as ei:
+                edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                                 keep_frames=1, noise_bank=(nx, nh))
+            e = ei.value
+            seen[split] = (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx, e.first_step)
+        print(f'NaN planted in draw {draw} of molecule {mol} (stops at call {q_end[mol]}): one launch {seen[False]}, split {seen[True]}')
+        assert seen[True] == seen[False] and (seen[True][0] | seen[True][1] | seen[True][2]) == {mol} and seen[True][3] == draw
