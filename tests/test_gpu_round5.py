@@ -542,3 +542,25 @@ def test_split_chain_reports_nans_of_either_launch_like_one_launch():
             seen[split] = (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx, e.first_step)
         print(f'NaN planted in draw {draw} of molecule {mol} (stops at call {q_end[mol]}): one launch {seen[False]}, split {seen[True]}')
         assert seen[True] == seen[False] and (seen[True][0] | seen[True][1] | seen[True][2]) == {mol} and seen[True][3] == draw
+
+
+@pytest.mark.parametrize('mag', [1e-4, 1e-2, 1e2, 1e4])
+@pytest.mark.parametrize('sizes,linkers', [([40, 12], [6, 3]), ([70, 20], [8, 4]), ([120, 12], [9, 4])])
+def test_forward_across_feature_magnitudes(sizes, linkers, mag):
+    """The a-priori / measured power-of-two scales of the f16 arithmetic over eight decades of feature magnitude, through EVERY
+    layer (the sweep of the test above drives the coordinate model only): a seeded model whose embedding is scaled by `mag` - node
+    features, messages, aggregates and node-MLP activations all move with it, into SiLU's linear and its dead range - on the
+    LDS-resident kernels (40 atoms), a team (70) and the HBM-resident kernels (120), against the oracle."""
+    nf, L = 9, 2
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=191)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd['dynamics.embedding.weight'] *= mag
+    sd['dynamics.embedding.bias'] *= mag
+    dyn.load_state_dict(sd, strict=True)
+    dyn.invalidate_packed()
+    inp, z, t = P.ragged_inputs(sizes, linkers, nf, seed=192)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    assert torch.isfinite(ref).all()
+    out = P.run_hip_forward(dyn, inp, z, t)
+    ev, eh = P.report(f'{sizes[0]} atoms, embedding x {mag:g}', out, ref, z)
+    assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
