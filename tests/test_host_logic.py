@@ -444,3 +444,35 @@ def test_found_nan_exception_from_index_sets_and_split_terms():
     t2 = synthetic.split_terms('f16x2', 128, cfg['n_layers'], fin, pairs, pc, nodes)
     assert 2.0 < t2 < 2.5          # the GCL edge models' second layer is ~80 % of the executed work
     assert synthetic.flops_executed(128, cfg['n_layers'], fin, pairs, pc, nodes) < synthetic.flops_min(128, cfg['n_layers'], fin, pairs, nodes)
+
+
+def test_split_plan_is_a_deterministic_feasible_function_of_the_sizes():
+    """``edm.split_plan`` (the static hand-over of a chain in two launches): deterministic, a function of the sizes alone; every
+    unfinished molecule stops strictly inside the chain; the second phase fits the chip (2 x teams + singles <= compute units);
+    the predicted makespan beats the single launch; a uniform batch, a batch that leaves the chip room for teams anyway and a
+    batch larger than the chip get no plan.  The C2 batch: the plan the benchmark runs (115 molecules of 43..50 atoms stop at
+    call 427 of 501)."""
+    from difflinker_amd import synthetic
+    from difflinker_amd.edm import forward_cost, split_plan
+    data, cfg = synthetic.make_batch('C2', seed=1000)
+    sizes = data['atom_mask'].squeeze(-1).sum(1).long().tolist()
+    linkers = data['linker_mask'].squeeze(-1).sum(1).long().tolist()
+    plan = split_plan(sizes, linkers, 501, 256, 6, 2)
+    assert plan == split_plan(list(sizes), list(linkers), 501, 256, 6, 2)
+    q_end, teams, singles = plan
+    assert singles == [] and len(teams) == 115 and min(q_end) == 427 and min(sizes[b] for b in teams) == 43
+    assert all(q_end[b] == 501 for b in range(256) if b not in teams) and all(0 < q_end[b] < 501 for b in teams)
+    c1 = [forward_cost(n, l, 6, 2, 1) for n, l in zip(sizes, linkers)]
+    c2 = [forward_cost(n, l, 6, 2, 2) for n, l in zip(sizes, linkers)]
+    total = max(q_end[b] * c1[b] for b in range(256)) + max((501 - q_end[b]) * c2[b] for b in teams)
+    assert total < 0.96 * max(c1) * 501
+    # with single compute units beside the teams (opt-in): more molecules stop, the chip is exactly full in the second phase
+    q2, t2, s2 = split_plan(sizes, linkers, 501, 256, 6, 2, allow_singles=True)
+    assert 2 * len(t2) + len(s2) <= 256 and len(s2) > 0 and set(t2).isdisjoint(s2) and all(0 < q2[b] < 501 for b in t2 + s2)
+    # no plan: nothing to hand over / no room / more molecules than compute units
+    assert split_plan([50] * 256, [8] * 256, 501, 256, 6, 2) is None
+    assert split_plan([50] * 200 + [49] * 56, [8] * 256, 501, 256, 6, 2) is None
+    assert split_plan(sizes + [40], linkers + [5], 501, 256, 6, 2) is None
+    # cost model: monotone in the number of pair-loop steps, a team of two is faster than one compute unit but less than twice
+    assert forward_cost(35, 6, 6, 2) < forward_cost(43, 6, 6, 2) < forward_cost(50, 6, 6, 2)
+    assert 1.3 < forward_cost(50, 8, 6, 2, 1) / forward_cost(50, 8, 6, 2, 2) < 2.0
