@@ -76,7 +76,8 @@ def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_
     if B > compute_units or B == 0:
         return None
     allow_singles = bool(allow_singles)
-    key = (tuple(sizes), tuple(linkers), n_calls, compute_units, n_layers, sublayers, min_gain, grid, bool(allow_singles))
+    key = (tuple(sizes), tuple(linkers), n_calls, compute_units, n_layers, sublayers, min_gain, grid, bool(allow_singles),
+           os.environ.get('DIFFLINKER_SPLIT_QSCALE', '1.0'))
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     table = {}
@@ -105,6 +106,10 @@ def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_
         if best is None or total < best[0]:
             best = (total, q_end.tolist(), teams.tolist(), singles.tolist())
     plan = None if best is None or best[0] > (1.0 - min_gain) * single else (best[1], best[2], best[3])
+    qscale = float(os.environ.get('DIFFLINKER_SPLIT_QSCALE', '1.0'))          # (calibration experiments: scripts/r5/ab_split_qscale.sh)
+    if plan is not None and qscale != 1.0:
+        stop = set(plan[1]) | set(plan[2])
+        plan = ([max(1, min(n_calls - 1, int(round(q * qscale)))) if b in stop else q for b, q in enumerate(plan[0])], plan[1], plan[2])
     if len(_PLAN_CACHE) > 64:
         _PLAN_CACHE.clear()
     _PLAN_CACHE[key] = plan
