@@ -35,7 +35,8 @@ from .noise import PredefinedNoiseSchedule
 SPLIT_CHAIN_DEFAULT = os.environ.get('DIFFLINKER_SPLIT_CHAIN', '1') == '1'
 
 
-def cus_or_none(dev):
+def compute_units(dev):
+    """compute units of the device (256 on an MI355X): what one-molecule-per-compute-unit launches fill"""
     return torch.cuda.get_device_properties(dev).multi_processor_count
 
 
@@ -532,10 +533,10 @@ class EDM(torch.nn.Module):
 
         # the static hand-over inside a ragged batch that fills the chip (split_plan): two launches
         plan = None
-        if team == 1 and over == 0 and self.split_chain and not self.dynamics._no_teams and bs <= cus_or_none(dev) and T >= 20:
+        if team == 1 and over == 0 and self.split_chain and not self.dynamics._no_teams and bs <= compute_units(dev) and T >= 20:
             sizes_h = nm.ne(0).sum(1).cpu().tolist()
             if max(sizes_h) <= int(lib.dl_max_atoms()) and min(sizes_h) > 0:
-                plan = split_plan(sizes_h, lm.ne(0).sum(1).cpu().tolist(), T + 1, cus_or_none(dev), self.dynamics.n_layers,
+                plan = split_plan(sizes_h, lm.ne(0).sum(1).cpu().tolist(), T + 1, compute_units(dev), self.dynamics.n_layers,
                                   int(getattr(self.dynamics, 'inv_sublayers', 2)), allow_singles=bool(self.split_singles))
         q_end_t = z_state = None
         if plan is not None:
