@@ -2174,7 +2174,8 @@ void pack_vec(float* dst, const float* src, int stride, double scale) {
 
 // ---- balanced packing (f16 modes; pack_layout.h: GS_*).  The hidden features of a two-layer MLP in the order of their
 // magnitude proxy, largest first: perm[p] = original index of the feature at position p; fac[p] = 2^n of its group of `group`
-// consecutive positions, n = how many whole binades the group's largest proxy sits below the overall largest (0 .. 40).
+// consecutive positions, n = how many whole binades the group's largest proxy sits below the overall largest (0 .. 40); the
+// features of a zero-padded narrow model are dealt out over all the groups (the group's largest stays its first position).
 // `on` = false (exact-fp32 mode): identity, all factors 1 - that mode packs exactly as before.
 struct Balance {
     int perm[HID];
@@ -2191,6 +2192,22 @@ void balance_hidden(Balance& b, const double* proxy, int group, bool on) {
     std::stable_sort(b.perm, b.perm + HID, [&](int x, int y) { return proxy[x] > proxy[y]; });
     const double top = proxy[b.perm[0]];
     if (!(top > 0.0) || !std::isfinite(top)) return;
+    // a model narrower than the kernels (hidden_nf < 128, zero-padded: proxy exactly 0) has fewer features to share the same
+    // number of groups: deal them out evenly - ceil(real / groups) to a group, still in order, the padding behind them - so that
+    // a group spans fewer binades instead of most groups holding nothing
+    int real = 0;
+    while (real < HID && proxy[b.perm[real]] > 0.0) ++real;
+    if (real < HID) {
+        const int groups = HID / group, per = (real + groups - 1) / groups;
+        int sorted[HID];
+        memcpy(sorted, b.perm, sizeof(sorted));
+        int pad = real;
+        for (int g = 0; g < groups; ++g)
+            for (int q = 0; q < group; ++q) {
+                const int j = g * per + q;
+                b.perm[g * group + q] = (q < per && j < real) ? sorted[j] : sorted[pad++];
+            }
+    }
     for (int p0 = 0; p0 < HID; p0 += group) {
         const double m = proxy[b.perm[p0]];                     // the group's largest
         int n = 0;

@@ -357,6 +357,34 @@ def test_pocket_forward_with_other_widths_depths_and_no_time_feature(hidden_nf, 
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
 
 
+@pytest.mark.parametrize('hidden_nf,seed,mag,sizes', [(32, 600030, 550.0, [47, 88, 62]), (32, 600009, 319.0, [47, 109, 21, 89, 81]),
+                                                      (64, 600041, 1.0, [30, 55])])
+def test_narrow_network_with_trained_like_weights(hidden_nf, seed, mag, sizes):
+    """A zero-padded narrow network has as many k-slabs / tiles for its hidden features' exponents as a 128-wide one and a
+    quarter of the features: packed in one corner, 32 features spread over ~20 binades shared TWO slab exponents and the error
+    of the f16x3 mode had a tail (scripts/r5/fuzz_forward.py, 50 seeds: up to 1.6e-5 against 1.7e-6 at width 128; the first two
+    cases here are its worst).  The packer deals the features out over all the groups (egnn_fc.hip: balance_hidden)."""
+    from difflinker_amd import Dynamics
+    nf, L, sub = 9, 3, 2
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=1, hidden_nf=hidden_nf, n_layers=L, inv_sublayers=sub,
+                   condition_time=False, norm_constant=1e-6)
+    sd = trained_like_state_dict(seeded_state_dict(nf + 1, hidden_nf, L, seed, inv_sublayers=sub, coord_gain=1.0), seed + 1)
+    sd['dynamics.embedding.weight'] = sd['dynamics.embedding.weight'] * mag
+    sd['dynamics.embedding.bias'] = sd['dynamics.embedding.bias'] * mag
+    dyn.load_state_dict(sd, strict=True)
+    dyn = dyn.to(P.dev())
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=1, hidden_nf=hidden_nf, n_layers=L, inv_sublayers=sub, condition_time=False)
+    inp, z, t = P.ragged_inputs(sizes, [min(s, 5) for s in sizes], nf, seed=seed + 2)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    assert torch.isfinite(ref).all()
+    for team in (1, 'auto'):
+        dyn.team = team
+        out = P.run_hip_forward(dyn, inp, z, t)
+        eh = rel_l2(out[..., 3:], ref[..., 3:])
+        print(f'narrow network, hidden {hidden_nf}, trained-like weights x {mag:g}, team {team}: node features rel-L2 {eh:.3e}')
+        assert eh <= 3e-6                                   # (before: 1.5e-5 on the first two cases)
+
+
 # ---- the HBM-resident kernels across magnitudes ------------------------------------------------------------------------------
 @pytest.mark.parametrize('mag', [1e-3, 1e-1, 1e2, 1e4, 1e6, 1e8])
 def test_hbm_resident_kernels_over_twenty_binades_of_magnitude(mag):
