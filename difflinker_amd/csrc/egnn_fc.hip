@@ -1188,8 +1188,12 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
         const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);     // senders: any atom of the molecule
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);            // >= |P_i| + |Q_j|
-        sa = scale_for(pqb + 4.0f * (x2 * cload(sc, GS_WRW) + x02 * cload(sc, GS_WDW)));        // (bounds with the slab exponents applied)
+        const float u1b = pqb + 4.0f * (x2 * cload(sc, GS_WRW) + x02 * cload(sc, GS_WDW));        // (bounds with the slab exponents applied)
+        sa = scale_for(u1b);
         accs = sa * cload(sc, 5);
+        // (h rows, hidden activations, r and d0 - geo_scale - of this pass; pack_layout.h: beyond_f16_range)
+        if (tid == 0 && (beyond_f16_range(u1b) || beyond_f16_range(hmax) || beyond_f16_range(4.0f * x2) || beyond_f16_range(4.0f * x02)))
+            atomicOr(&v.misc[1], NAN_RANGE | 3);
     }
     // (edge attention is a KERNEL variant, not a branch: its pair loop keeps the 64 messages of a step until the logit is known
     // and spills ~80 registers, which would set the scratch size - and the register pressure around the call - of every launch)
@@ -1241,7 +1245,9 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     // bounds: |y3| <= L1(W3a') max|h| + L1(W3b') max|agg| + max|b3'|  >= |t| ;  |h_new| <= max|h| + L1(W4') |t| + max|b4|
     const float y3b = cload(sc, SC_L1_W3A) * hmax + cload(sc, SC_L1_W3B) * aggmax + cload(sc, SC_B3);
     const float s_t = (PREC != 0) ? scale_for(y3b) : 1.0f;
-    const float s_hn = (PREC != 0) ? scale_for(hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4)) : 1.0f;
+    const float hnb = hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4);
+    const float s_hn = (PREC != 0) ? scale_for(hnb) : 1.0f;
+    if (PREC != 0 && tid == 0 && (beyond_f16_range(aggmax) || beyond_f16_range(y3b) || beyond_f16_range(hnb))) atomicOr(&v.misc[1], NAN_RANGE | 3);
     // (W3b': one weight scale per output tile; the hidden layer t of tile nt is written times s_t * 2^n_nt, W4' carries 2^-n per column)
     const float inv1 = (PREC != 0) ? inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)) : 1.0f, inv2 = (PREC != 0) ? inv_pow2(s_t * cload(sc, 4)) : 1.0f;
     const float s_tn = (PREC != 0) ? s_t * cload(sc, GS_NT + nt) : 1.0f;
@@ -1364,6 +1370,8 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
         if (PREC != 0) {
             sa = scale_for(u1b);
             accs = sa * cload(sc, 2);
+            if (q.tid == 0 && (beyond_f16_range(u1b) || beyond_f16_range(hmax) || beyond_f16_range(4.0f * x2) || beyond_f16_range(4.0f * x02)))
+                atomicOr(&v.misc[1], NAN_RANGE | 3);
         }
         // The pass runs for the receivers inside the linker mask only: the reference multiplies every other atom's sum by zero
         // (egnn.py:113-116).  That is the reference's result exactly as long as the skipped sums are FINITE - an inf or NaN there
@@ -1520,7 +1528,10 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         const float s0 = (PREC != 0) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
         for (int e = tid; e < nown * 32; e += THREADS)
             put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), *reinterpret_cast<const float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)), s0);
-        if (PREC != 0 && tid == 0) v.fmax[FS_HS] = __float_as_uint(s0);
+        if (PREC != 0 && tid == 0) {
+            v.fmax[FS_HS] = __float_as_uint(s0);
+            if (beyond_f16_range(__uint_as_float(v.fmax[FM_H0]))) atomicOr(&v.misc[1], NAN_RANGE | 3);
+        }
     }
     __syncthreads();
     prof_event(pf, w, lane, 2);

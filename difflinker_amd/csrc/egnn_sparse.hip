@@ -89,6 +89,9 @@ inline PkWs carve(void* base, int B, int N) {
 // edge kernel, read by pk_xupdate_kernel), [4..6] float bits of the batch-wide maxima of |h|, |x|^2, |x0|^2 (atomicMax; never reset
 // inside a forward: conservative) - what the proof behind skipping the masked coordinate sums needs (pk_edge_kernel<EQUIV>)
 constexpr int TW_FULL = 2, TW_HMAX = 4, TW_X2 = 5, TW_X02 = 6;
+// [7]: some f16-mode scale of this forward came from a bound beyond the fp16 range (pack_layout.h: beyond_f16_range) - the scales
+// here belong to tiles, not to molecules, so pk_out_kernel reports every molecule of the call (NAN_RANGE | x | h)
+constexpr int TW_RANGE = 7;
 // batch-wide maximum of non-negative floats (as bits: they order like the values, NaN above all): the atomic is issued only when
 // the word - read relaxed, possibly stale, i.e. LOWER - does not already hold as much; after the first few waves of a kernel nobody
 // issues one (19 k atoms x 128 features of atomics on ONE address cost a forward of the pocket configuration a third of its time)
@@ -362,6 +365,7 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         if (PREC == 1) {
             const float sw3a = sc[GS_SW_W3A + nt], sw3b = sc[GS_SW_W3B + nt];     // one weight scale per output tile (balanced packing)
             const float S = fminf(s_h * sw3a, scale_for(__uint_as_float(mx[1])) * sw3b);
+            if (tid == 0 && (beyond_f16_range(__uint_as_float(mx[0])) || beyond_f16_range(__uint_as_float(mx[1])))) w.total[TW_RANGE] = 1;
             s1 = S * inv_pow2(sw3a); s2 = S * inv_pow2(sw3b); inv = inv_pow2(S);
         }
         floatx16 acc = splat16(PREC == 0 ? b3 : 0.0f);
@@ -386,7 +390,10 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         __syncthreads();
         const float b4 = vecs[5 * HID + 32 * nt + c];
         float s_t = 1.0f, inv4 = 1.0f;
-        if (PREC == 1) { s_t = scale_for(__uint_as_float(mx[2])); inv4 = inv_pow2(s_t * sc[4]); }
+        if (PREC == 1) {
+            s_t = scale_for(__uint_as_float(mx[2])); inv4 = inv_pow2(s_t * sc[4]);
+            if (tid == 0 && beyond_f16_range(__uint_as_float(mx[2]))) w.total[TW_RANGE] = 1;
+        }
         floatx16 hn;
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) hn[reg] = (PREC == 0) ? hL[acc_row(reg, hh) * LDT + 32 * nt + c] + b4 : 0.0f;
@@ -411,7 +418,10 @@ pk_node_kernel(PkDims d, PkWs w, const float* __restrict__ post, const float* __
         }
         wg_max(&mx[3], nmax, lane);
         __syncthreads();
-        if (PREC == 1) s_h = scale_for(__uint_as_float(mx[3]));
+        if (PREC == 1) {
+            s_h = scale_for(__uint_as_float(mx[3]));
+            if (tid == 0 && beyond_f16_range(__uint_as_float(mx[3]))) w.total[TW_RANGE] = 1;
+        }
         if (tid == 0) gmax_update(w.total, TW_HMAX, __uint_as_float(mx[3]));       // batch-wide max |h| (pk_edge_kernel<EQUIV>)
     }
     if (pre_units) {
@@ -678,7 +688,9 @@ pk_edge_kernel(PkDims d, PkWs w, const float* __restrict__ wimg, const float* __
             // i.e. converted to int and back - a bound below 1 became 0 (scale 2^60: every activation saturated at the fp16 maximum)
             // and one above 2^31 became 2^31; found by the magnitude sweep of scripts/r5/debug_range.py, pinned by
             // tests/test_gpu_round5.py::test_hbm_resident_kernels_over_twenty_binades_of_magnitude)
-            const float sa = scale_for(__int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bound))));
+            const float bound_u = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bound)));
+            const float sa = scale_for(bound_u);
+            if (beyond_f16_range(bound_u) && lane == 0) w.total[TW_RANGE] = 1;
             const float accs = sa * sc[sw_index], inv = inv_pow2(accs);
             // accumulators start from the inline constant 0; the bias joins in the (exact) rescaling fma
             acc0 = splat16(0.0f); acc1 = splat16(0.0f); acc2 = splat16(0.0f); acc3 = splat16(0.0f);
@@ -895,6 +907,7 @@ __global__ void pk_out_kernel(PkDims d, PkWs w, const float* __restrict__ wp, fl
     }
     out[size_t(v) * d.D + k] = val;
     if (val != val) atomicOr(&nan_flags[v / d.N], bit);
+    if (k == 0 && v % d.N == 0 && w.total[TW_RANGE] != 0) atomicOr(&nan_flags[v / d.N], NAN_RANGE | 3);
 }
 
 thread_local int g_sparse_last_hip = 0;

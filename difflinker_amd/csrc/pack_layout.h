@@ -197,6 +197,14 @@ __device__ __forceinline__ float scale_for(float bound) {
     return __uint_as_float(unsigned(f) << 23);
 }
 
+// A bound of 2^75 (3.8e22) or more - +inf included - is beyond the clamp: a value behind it may exceed the fp16 range once scaled,
+// and v_cvt_pkrtz would SATURATE it at 65504 - a finite wrong number, not an inf.  Every kernel that derives a scale from a
+// run-time bound reports that instead (nan_flags: NAN_RANGE | x | h - the molecule's denoiser output is void: utils.FoundNaNException
+// with f16_range_idx set; precision='fp32' has no such limit).  A NaN bound is not reported here: it comes from NaN data, which
+// travels through the arithmetic itself.
+constexpr int NAN_RANGE = 16;
+__device__ __forceinline__ bool beyond_f16_range(float bound) { return bound >= 0x1p75f; }
+
 // exact reciprocal of a power of two
 __device__ __forceinline__ float inv_pow2(float s) { return __uint_as_float(0x7f000000u - __float_as_uint(s)); }
 

@@ -457,7 +457,8 @@ class EDM(torch.nn.Module):
                 except utils.FoundNaNException as e:
                     rows = idx.tolist()
                     nan_sets.append((int(getattr(e, 'first_step', 0)),
-                                     tuple({rows[k] for k in s_} for s_ in (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx))))
+                                     tuple({rows[k] for k in s_} for s_ in (e.x_h_nan_idx, e.only_x_nan_idx, e.only_h_nan_idx,
+                                                                            getattr(e, 'f16_range_idx', ())))))
                     return None
             for idx, team in fused:
                 bank = None if philox else (noise_bank[0][:, idx].contiguous(), noise_bank[1][:, idx].contiguous())
@@ -476,7 +477,7 @@ class EDM(torch.nn.Module):
             if nan_sets:
                 first = min(step for step, _ in nan_sets)
                 err = utils.FoundNaNException.from_index_sets(*(set().union(*(s_[k] for step, s_ in nan_sets if step == first))
-                                                                for k in range(3)))
+                                                                for k in range(4)))
                 err.first_step = first
                 raise err
         finally:

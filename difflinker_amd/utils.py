@@ -14,14 +14,22 @@ class FoundNaNException(Exception):
     (``generate.py:154-161``) catch it and retry the batch.
     """
 
-    def __init__(self, x=None, h=None, x_nan_idx=None, h_nan_idx=None):
+    def __init__(self, x=None, h=None, x_nan_idx=None, h_nan_idx=None, f16_range_idx=()):
         x_nan_idx = self.find_nan_idx(x) if x_nan_idx is None else set(x_nan_idx)
         h_nan_idx = self.find_nan_idx(h) if h_nan_idx is None else set(h_nan_idx)
         self.x_h_nan_idx = x_nan_idx & h_nan_idx
         self.only_x_nan_idx = x_nan_idx.difference(h_nan_idx)
         self.only_h_nan_idx = h_nan_idx.difference(x_nan_idx)
-        super().__init__(f'NaN in denoiser output: x&h {sorted(self.x_h_nan_idx)}, '
-                         f'x only {sorted(self.only_x_nan_idx)}, h only {sorted(self.only_h_nan_idx)}')
+        # not in the reference: molecules whose activations left the range of the f16 arithmetic modes (a magnitude bound of
+        # 2^75 ~ 3.8e22 or more, e.g. coordinates beyond ~1e10: pack_layout.h, beyond_f16_range).  Their output is void and they
+        # are listed under x&h as well, so the reference's callers re-sample them like any NaN; precision='fp32' has no limit.
+        self.f16_range_idx = set(f16_range_idx)
+        msg = (f'NaN in denoiser output: x&h {sorted(self.x_h_nan_idx)}, '
+               f'x only {sorted(self.only_x_nan_idx)}, h only {sorted(self.only_h_nan_idx)}')
+        if self.f16_range_idx:
+            msg += (f"; of these, {sorted(self.f16_range_idx)} left the range of the f16 arithmetic modes (|value| bound >= 3.8e22): "
+                    f"precision='fp32' computes them")
+        super().__init__(msg)
 
     @staticmethod
     def find_nan_idx(z):
@@ -31,16 +39,17 @@ class FoundNaNException(Exception):
         return set(torch.nonzero(bad).flatten().tolist())
 
     @classmethod
-    def from_index_sets(cls, x_h, only_x, only_h):
+    def from_index_sets(cls, x_h, only_x, only_h, f16_range=()):
         """Build from the three index sets themselves (a batch sampled in parts: sets re-numbered to the whole batch)."""
-        return cls(x_nan_idx=set(x_h) | set(only_x), h_nan_idx=set(x_h) | set(only_h))
+        return cls(x_nan_idx=set(x_h) | set(only_x), h_nan_idx=set(x_h) | set(only_h), f16_range_idx=f16_range)
 
     @classmethod
     def from_flags(cls, flags):
-        """Build from the per-molecule device flag word (bit0: x NaN, bit1: h NaN)."""
+        """Build from the per-molecule device flag word (bit0: x NaN, bit1: h NaN, bit4: beyond the f16 range - set with both)."""
         flags = flags.tolist() if hasattr(flags, 'tolist') else list(flags)
         return cls(x_nan_idx={i for i, f in enumerate(flags) if f & 1},
-                   h_nan_idx={i for i, f in enumerate(flags) if f & 2})
+                   h_nan_idx={i for i, f in enumerate(flags) if f & 2},
+                   f16_range_idx={i for i, f in enumerate(flags) if f & 16})
 
 
 def set_deterministic(seed):

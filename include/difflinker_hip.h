@@ -142,7 +142,11 @@ int32_t dl_max_atoms(void);
  *   context     device f32 [B,N,ctx] or NULL when ctx == 0
  *   out         device [B,N,3+nf]   eps_hat = cat[vel, h_final]; padded rows are written as 0
  *   nan_flags   device int32 [B]    bit0: NaN in vel, bit1: NaN in h_final, bit2: too many atoms
- *                                   (the caller raises FoundNaNException, src/egnn.py:441-442) */
+ *                                   (the caller raises FoundNaNException, src/egnn.py:441-442);
+ *                                   bit4 (f16 modes only, always with bit0 | bit1): a magnitude bound of this molecule's
+ *                                   activations reached 2^75 (3.8e22) - beyond the scales' range the fp16 operands would
+ *                                   saturate silently, so `out` is void; DL_PRECISION_FP32 has no such limit.  The radius-graph
+ *                                   kernels scale per tile, not per molecule: they report every molecule of the call */
 int32_t dl_egnn_forward_fc(const dl_model* m, int32_t B, int32_t N,
                            const float* xh, const float* t, int32_t t_is_scalar,
                            const int8_t* node_mask, const float* linker_mask, const int8_t* edge_mask,

@@ -592,3 +592,73 @@ def test_forward_across_feature_magnitudes(sizes, linkers, mag):
     out = P.run_hip_forward(dyn, inp, z, t)
     ev, eh = P.report(f'{sizes[0]} atoms, embedding x {mag:g}', out, ref, z)
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+
+
+# ---- beyond the range of the f16 modes: loud, never a saturated number ------------------------------------------------------------
+def _far_apart_case(spread, sizes, linkers):
+    """A seeded model on molecules whose atoms lie `spread` apart: squared distances of spread^2 enter every edge / coordinate
+    model (radial and d0: egnn.py:160-163, 219-222)."""
+    nf, L = 9, 2
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=211)
+    inp, z, t = P.ragged_inputs(sizes, linkers, nf, seed=212)
+    z = z.clone()
+    z[..., :3] *= spread
+    return dyn, sd, cfg, inp, z, t
+
+
+@pytest.mark.parametrize('sizes,linkers,team', [([20, 12], [5, 4], 1), ([20, 12], [5, 4], 'auto'), ([70, 20], [8, 4], 'auto'),
+                                               ([120, 12], [9, 4], 'auto')])
+@pytest.mark.parametrize('spread', [1e6, 1e9, 3e10])
+def test_coordinates_beyond_the_f16_range_are_reported_not_saturated(sizes, linkers, team, spread):
+    """scripts/r5/fuzz_chain.py, seed 300109: a chain whose denoiser threw the atoms 1e10 apart - squared distances of 1e21 times
+    weights of ~30, a bound beyond the 2^-60 clamp of the f16x3 scales - came back FINITE and wrong (3e-3, eight atom types):
+    v_cvt_pkrtz saturates at 65504 instead of overflowing, and the round-4 pin of the clamp (test_gpu_round4.py) had only driven
+    the node features there, where the arithmetic happens to end in NaN.  Now every scale that comes from a run-time bound checks
+    it (pack_layout.h: beyond_f16_range; nan_flags bit 4): within the range (atoms 1e6 apart) the result is the oracle's, beyond
+    it (3e10: the squared distances alone exceed 3.8e22 - a little further and the fp32 oracle overflows too; at 1e9 the bound,
+    squared distance x weights, decides) the call raises ``FoundNaNException`` naming the molecules (``f16_range_idx``) - on one
+    compute unit, on teams, on the HBM-resident kernels - and the exact-fp32 mode computes the oracle's result at every magnitude."""
+    from difflinker_amd.utils import FoundNaNException
+    dyn, sd, cfg, inp, z, t = _far_apart_case(spread, sizes, linkers)
+    dyn.team = team
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    assert torch.isfinite(ref).all(), 'fp32 holds these magnitudes'
+    for precision in ('fp32', 'f16x3'):
+        dyn.precision = precision
+        try:
+            out = P.run_hip_forward(dyn, inp, z, t)
+        except FoundNaNException as e:
+            print(f'[{sizes[0]} atoms, team {team}, atoms {spread:g} apart, {precision}] {e}')
+            assert precision == 'f16x3' and spread >= 1e9, 'only the f16 modes, and only beyond their range, may give up'
+            assert e.f16_range_idx and e.f16_range_idx <= e.x_h_nan_idx and not e.only_x_nan_idx and not e.only_h_nan_idx
+            continue
+        eh = rel_l2(out[..., 3:], ref[..., 3:])
+        ev = rel_l2(out[..., :3], ref[..., :3])
+        print(f'[{sizes[0]} atoms, team {team}, atoms {spread:g} apart, {precision}] rel-L2 h {eh:.3e} vel {ev:.3e}')
+        assert eh <= 1e-5 and ev <= 1e-4, f'{precision} returned finite numbers that are not the reference\'s'
+        assert precision == 'fp32' or spread < 3e10, 'squared distances of 1e23 cannot have fitted the f16 scales'
+
+
+def test_pocket_coordinates_beyond_the_f16_range_are_reported():
+    """The same on the radius-graph kernels: their scales belong to tiles, so the report names every molecule of the call."""
+    from difflinker_amd.utils import FoundNaNException
+    nf = 9
+    dyn, sd, cfg = P.make_pocket_dynamics(nf, 2, seed=221)
+    inp, z, t = P.pocket_inputs(batch=2, n_frag=12, n_pocket=60, linker=(4, 7), nf=nf, seed=222)
+    for spread, beyond in ((1.0, False), (3e10, True)):
+        zz = z.clone()
+        zz[..., :3] *= spread              # (atoms 1e11 apart: the radius edges are gone, the ligand's fully-connected ones carry 1e23; beyond 1e11 the oracle overflows)
+        ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, zz, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        assert torch.isfinite(ref).all()
+        for precision in ('fp32', 'f16x3'):
+            dyn.precision = precision
+            dyn.invalidate_packed()
+            try:
+                out = P.run_hip_forward(dyn, inp, zz, t)
+            except FoundNaNException as e:
+                print(f'[pockets, coordinates x {spread:g}, {precision}] {e}')
+                assert precision == 'f16x3' and beyond and e.f16_range_idx == {0, 1}
+                continue
+            eh = rel_l2(out[..., 3:], ref[..., 3:])
+            print(f'[pockets, coordinates x {spread:g}, {precision}] rel-L2 h {eh:.3e}')
+            assert eh <= 1e-5 and not (beyond and precision == 'f16x3')
