@@ -38,6 +38,12 @@ def draw(seed):
     c['keep'] = int(rng.choice([1, 2, max(1, c['T'] // 2), c['T']]))
     nmol, kind = int(rng.integers(1, 9)), rng.random()
     hi = 130 if kind < 0.1 else (110 if kind < 0.35 else 55)
+    if seed >= 50 * 100000:
+        # --seed 50 and up: chains long enough for the static hand-over (EDM._sample_chain_fused: T >= 20, one compute unit per
+        # molecule) on ragged batches of small molecules - two launches, the second on teams of two, state handed over in HBM
+        c['T'], c['team'], c['split'], hi = int(rng.integers(20, 37)), '1', True, 55
+        c['keep'] = int(rng.choice([1, 2, c['T'] // 3]))
+        nmol = int(rng.integers(3, 15))
     c['sizes'] = [int(rng.integers(2, hi + 1)) for _ in range(nmol)]
     if rng.random() < 0.15:                                     # all the same size: no molecule finishes before another
         c['sizes'] = [c['sizes'][0]] * nmol
@@ -147,7 +153,7 @@ if __name__ == '__main__':
     else:
         store = torch.load(a.check)
         from difflinker_amd.utils import FoundNaNException
-        bad, n, out_of_range = [], 0, 0
+        bad, n, out_of_range, planned = [], 0, 0, 0
         for seed, want in store.items():
             c = draw(seed)
             if want is None:
@@ -198,8 +204,12 @@ if __name__ == '__main__':
                 efr = rel_l2(got[1:], want[1:]) if got.shape[0] > 1 else 0.0
                 frag = max_abs(got[0, :, :, :3] * fm, want[0, :, :, :3] * fm)
                 eo = rel_l2(other[0, :, :, :3] * lm, got[0, :, :, :3] * lm)
-                # (an exploding chain: the bar is five times what the reference's own fp32 arithmetic loses against fp64 on it)
-                if ex > max(P.CHAIN_TOL, 5 * cond) or efr > max(P.CHAIN_TOL, 5 * cond):
+                # (an exploding chain - some molecule's atoms fly 1e4 and more apart, the velocity grows like |x|^3.6 and every call
+                # multiplies a relative difference by that power: profiles/r05/fuzz_chain.log, debug_chain_calls.log, where each
+                # single forward is within 1e-7 .. 1e-6 of fp64 - is judged against ten times what the reference's own fp32
+                # arithmetic loses against fp64 on it, and the two launch modes against each other by the same bar)
+                bar = max(P.CHAIN_TOL, 10 * cond)
+                if ex > bar or efr > bar:
                     why.append('chain error')
                 if mism:
                     why.append(f'{mism} atom types differ')
@@ -207,14 +217,18 @@ if __name__ == '__main__':
                     why.append(f'fragment atoms moved by {frag:.1e}')
                 if not torch.equal(got, again):
                     why.append('not repeatable bit for bit')
-                if eo > 1e-5 or not torch.equal(other[0, :, :, 3:], got[0, :, :, 3:]):
+                if eo > (bar if cond else 1e-5) or not torch.equal(other[0, :, :, 3:], got[0, :, :, 3:]):
                     why.append(f'one launch vs two launches: {eo:.1e}')
+                if c['seed'] >= 50 * 100000:
+                    from difflinker_amd import edm as edm_mod
+                    plan = edm_mod.split_plan(c['sizes'], c['linkers'], c['T'] + 1, torch.cuda.get_device_properties(P.dev()).multi_processor_count, c['L'], c['sub'])
+                    planned += plan is not None
                 line = f'x {ex:.2e} frames {efr:.2e} split-vs-not {eo:.1e}' + (f' [exploding chain: fp32 oracle {cond:.1e} from fp64]' if cond else '')
             if why:
                 bad.append(f'{"; ".join(why)} | {line if got.shape == want.shape else ""} | {describe(c)}')
                 print('FAIL', bad[-1], flush=True)
             else:
                 print('ok  ', line, describe(c), flush=True)
-        print(f'{n} chains checked in {time.time() - t0:.0f} s: {n - len(bad) - out_of_range} ok, {out_of_range} reported beyond the f16 range, {len(bad)} failures')
+        print(f'{n} chains checked in {time.time() - t0:.0f} s: {n - len(bad) - out_of_range} ok, {out_of_range} reported beyond the f16 range, {len(bad)} failures' + (f' ({planned} of the finite chains ran in two launches)' if planned else ''))
         for b in bad:
             print('FAILED:', b)
