@@ -360,6 +360,8 @@ class EDM(torch.nn.Module):
         else:
             assert keep_frames <= self.T
         bs, n = x.size(0), x.size(1)
+        if bs == 0:                                 # an empty batch is an empty chain in the reference (every op runs on empty tensors)
+            return torch.zeros((keep_frames, 0, n, self.n_dims + self.in_node_nf), dtype=x.dtype, device=x.device)
         if not self._fused_ok():
             philox_draws = None
             if noise_bank is None and self.noise_source == 'philox':
@@ -826,6 +828,8 @@ class InpaintingEDM(EDM):
         nf, T = self.in_node_nf, self.T
         keep_frames = T if keep_frames is None else keep_frames
         assert keep_frames <= T
+        if bs == 0:
+            return torch.zeros((keep_frames, 0, n, self.n_dims + nf), dtype=x.dtype, device=dev)
         if philox:
             noise_x, noise_h = self.philox_noise_bank(bs, n, dev, mol_offset=mol_offset, n_draws=1 + 2 * T + 2)
         elif noise_bank is None:

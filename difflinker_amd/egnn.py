@@ -531,6 +531,8 @@ class Dynamics(nn.Module):
         Returns eps_hat (B, N, 3 + nf) = cat[vel, h_final]; raises ``utils.FoundNaNException``.
         """
         assert self.graph_type == 'FC'
+        if xh.shape[0] == 0:                       # an empty batch: the reference's empty edge list gives an empty output (egnn.py:449-464)
+            return torch.zeros_like(xh)
 
         def run():
             prep = self.prepare(node_mask, linker_mask, edge_mask, context)
@@ -617,6 +619,8 @@ class DynamicsWithPockets(Dynamics):
         return out, flags
 
     def forward(self, t, xh, node_mask, linker_mask, edge_mask, context):
+        if xh.shape[0] == 0:
+            return torch.zeros_like(xh)
         out, flags = self.launch(self.prepare(node_mask, linker_mask, edge_mask, context), t, xh)
         self._raise_on_flags(flags)
         return out

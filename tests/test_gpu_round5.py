@@ -662,3 +662,62 @@ def test_pocket_coordinates_beyond_the_f16_range_are_reported():
             eh = rel_l2(out[..., 3:], ref[..., 3:])
             print(f'[pockets, coordinates x {spread:g}, {precision}] rel-L2 h {eh:.3e}')
             assert eh <= 1e-5 and not (beyond and precision == 'f16x3')
+
+
+# ---- edges of the input domain -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['one step', 'a molecule without linker atoms, every frame kept', 'no padding row'])
+def test_chain_edge_cases_against_the_oracle(case):
+    """A chain of ONE step (T = 1: the initial z, one denoising step, the decode), a batch one of whose molecules has nothing
+    to sample (its linker mask is empty: the denoiser still sees it, every frame returns its fragment unchanged) with EVERY frame
+    kept (keep_frames = T), and a batch whose molecules all fill the padded width."""
+    sizes, linkers, T, keep, empty = {'one step': ([12, 7], [4, 2], 1, 1, None),
+                                      'a molecule without linker atoms, every frame kept': ([12, 9, 7], [4, 3, 2], 6, 6, 1),
+                                      'no padding row': ([5, 5, 5], [2, 2, 2], 5, 1, None)}[case]
+    nf, L = 8, 2
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=231)
+    inp, _, _ = P.ragged_inputs(sizes, linkers, nf, seed=232)
+    if empty is not None:
+        inp['fragment_mask'][empty] = inp['node_mask'][empty].to(inp['fragment_mask'].dtype)
+        inp['linker_mask'][empty] = 0
+    B, N = inp['x'].shape[:2]
+    edm = _edm(dyn, nf, T)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=233)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'], inp['edge_mask'],
+                            inp['context'], bank, keep_frames=keep)
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    for team in (1, 'auto'):
+        dyn.team = team
+        got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                               keep_frames=keep, noise_bank=bank.stacked()).cpu()
+        P.check_chain(f'{case}, team {team}', got, want, inp)
+        if empty is not None:
+            assert torch.equal(got[:, empty], want[:, empty]), 'nothing to sample: the fragment, bit for bit, in every frame'
+
+
+def test_an_empty_batch_is_an_empty_chain():
+    """B = 0: every op of the reference runs on empty tensors (its edge list is empty: egnn.py:449-464) and the chain comes back
+    with no molecule in it; so it does here - from the denoiser, the sampler, the inpainting sampler and the pocket denoiser."""
+    from difflinker_amd import InpaintingEDM, Dynamics
+    nf, N, T = 8, 10, 4
+    dyn, _, _ = P.make_dynamics(nf, 1, 1, seed=241)
+    d = P.dev()
+    z = dict(x=torch.zeros(0, N, 3), h=torch.zeros(0, N, nf), node_mask=torch.zeros(0, N, 1), fragment_mask=torch.zeros(0, N, 1),
+             linker_mask=torch.zeros(0, N, 1), edge_mask=torch.zeros(0, 1), context=torch.zeros(0, N, 1))
+    g = {k: v.to(d) for k, v in z.items()}
+    out = dyn.forward(torch.zeros(0, 1, device=d), torch.zeros(0, N, 3 + nf, device=d), g['node_mask'], g['linker_mask'], g['edge_mask'], g['context'])
+    assert tuple(out.shape) == (0, N, 3 + nf)
+    edm = _edm(dyn, nf, T)
+    chain = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'], keep_frames=2)
+    assert tuple(chain.shape) == (2, 0, N, 3 + nf)
+    cdyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=1, hidden_nf=128, n_layers=1, norm_constant=1e-6, centering=True).to(d)
+    inp_edm = InpaintingEDM(cdyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+                            loss_type='l2', norm_values=[1, 4, 10]).to(d)
+    inp_edm.T = T
+    chain = inp_edm.sample_chain(g['x'], g['h'], g['node_mask'], g['edge_mask'], g['fragment_mask'], g['linker_mask'], g['context'], keep_frames=3)
+    assert tuple(chain.shape) == (3, 0, N, 3 + nf)
+    pdyn, _, _ = P.make_pocket_dynamics(nf, 1, seed=242)
+    out = pdyn.forward(torch.zeros(0, 1, device=d), torch.zeros(0, N, 3 + nf, device=d), g['node_mask'], g['linker_mask'],
+                       torch.zeros(0, device=d), torch.zeros(0, N, 2, device=d))
+    assert tuple(out.shape) == (0, N, 3 + nf)

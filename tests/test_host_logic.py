@@ -476,3 +476,16 @@ def test_split_plan_is_a_deterministic_feasible_function_of_the_sizes():
     # cost model: monotone in the number of pair-loop steps, a team of two is faster than one compute unit but less than twice
     assert forward_cost(35, 6, 6, 2) < forward_cost(43, 6, 6, 2) < forward_cost(50, 6, 6, 2)
     assert 1.3 < forward_cost(50, 8, 6, 2, 1) / forward_cost(50, 8, 6, 2, 2) < 2.0
+
+
+def test_nan_flag_word_decodes_into_the_references_index_sets_and_the_f16_range_set():
+    """include/difflinker_hip.h: bit0 NaN in the velocity, bit1 in the node features (utils.py:274-289: x&h / x only / h only),
+    bit4 - always with both - a magnitude bound beyond the range of the f16 arithmetic modes."""
+    from difflinker_amd.utils import FoundNaNException
+    e = FoundNaNException.from_flags([0, 1, 2, 3, 19, 0])
+    assert e.only_x_nan_idx == {1} and e.only_h_nan_idx == {2} and e.x_h_nan_idx == {3, 4} and e.f16_range_idx == {4}
+    assert "precision='fp32'" in str(e) and '[4]' in str(e)
+    e = FoundNaNException.from_flags(torch.tensor([3, 0], dtype=torch.int32))
+    assert e.x_h_nan_idx == {0} and not e.f16_range_idx and 'range' not in str(e)
+    e = FoundNaNException.from_index_sets({5}, {1}, set(), {5})
+    assert e.x_h_nan_idx == {5} and e.only_x_nan_idx == {1} and e.f16_range_idx == {5}
