@@ -489,3 +489,46 @@ def test_nan_flag_word_decodes_into_the_references_index_sets_and_the_f16_range_
     assert e.x_h_nan_idx == {0} and not e.f16_range_idx and 'range' not in str(e)
     e = FoundNaNException.from_index_sets({5}, {1}, set(), {5})
     assert e.x_h_nan_idx == {5} and e.only_x_nan_idx == {1} and e.f16_range_idx == {5}
+
+
+def _gloo_uneven_worker(rank, world, port, tmp):
+    import torch.distributed as dist
+    from difflinker_amd.distributed import sample_chain_sharded, shard_bounds
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=rank, world_size=world)
+    B, N, nf, K = 2, 6, 4, 2                      # fewer molecules than ranks: the last rank's shard is EMPTY
+    g = torch.Generator().manual_seed(3)
+    inp = dict(x=torch.randn(B, N, 3, generator=g), h=torch.randn(B, N, nf, generator=g), node_mask=torch.ones(B, N, 1),
+               fragment_mask=torch.ones(B, N, 1), linker_mask=torch.zeros(B, N, 1),
+               edge_mask=torch.arange(B).repeat_interleave(N),          # the pockets' batch-id vector [B*N] (datasets.py:359-364)
+               context=torch.randn(B, N, 2, generator=g))
+    lo, hi = shard_bounds(B, rank, world)
+
+    class StandIn:
+        coef_batch = None
+        team_batch = None
+        noise_source = 'philox'
+
+        def sample_chain(self, x, h, node_mask, fragment_mask, linker_mask, edge_mask, context, keep_frames=None, mol_offset=0):
+            assert x.shape[0] == hi - lo and mol_offset == lo and self.coef_batch == B
+            if x.shape[0]:
+                ids = edge_mask.view(x.shape[0], N)
+                assert torch.equal(ids, torch.arange(x.shape[0]).repeat_interleave(N).view(-1, N)), 're-based to the shard'
+            frame = torch.cat([x + float(mol_offset), h], dim=2)
+            return torch.stack([frame * (k + 1) for k in range(keep_frames)])
+
+    full = sample_chain_sharded(StandIn(), inp, keep_frames=K)
+    want = torch.stack([torch.cat([inp['x'] + torch.tensor([0.0, 1.0]).view(B, 1, 1), inp['h']], dim=2) * (k + 1) for k in range(K)])
+    assert full.shape == (K, B, N, 3 + nf) and torch.equal(full, want)
+    if rank == world - 1:
+        assert hi == lo, 'this rank sampled nothing and still took part in the collective'
+        torch.save(full, os.path.join(tmp, 'uneven.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharding_with_fewer_molecules_than_ranks_and_batch_id_edge_masks(tmp_path):
+    """world_size 3, two molecules: one rank's shard is empty (an empty batch is an empty chain, like the reference) and it still
+    joins the all-gather; the pockets' batch-id ``edge_mask`` of a shard is re-based to start at 0; every rank gets the full frames."""
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_gloo_uneven_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), 'uneven.pt'))
