@@ -721,3 +721,46 @@ def test_an_empty_batch_is_an_empty_chain():
     out = pdyn.forward(torch.zeros(0, 1, device=d), torch.zeros(0, N, 3 + nf, device=d), g['node_mask'], g['linker_mask'],
                        torch.zeros(0, device=d), torch.zeros(0, N, 2, device=d))
     assert tuple(out.shape) == (0, N, 3 + nf)
+
+
+@pytest.mark.parametrize('team', [1, 'auto'])
+def test_real_atoms_anywhere_among_the_padding_rows(team):
+    """The reference takes any node mask (collate pads at the end, templates put the linker last - but nothing in egnn.py /
+    edm.py relies on it).  The same molecules with their rows - real atoms and padding alike - shuffled, masks and the [B, N, N]
+    edge mask shuffled along: the denoiser's output and the sampler's chain are the shuffled ones (one compute unit per
+    molecule, teams, the HBM-resident kernels at 120 atoms; the sums run in another order: fp32 rounding)."""
+    nf, L, T = 8, 2, 5
+    dyn, sd, cfg = P.make_dynamics(nf, 1, L, seed=251)
+    dyn.team = team
+    inp, z, t = P.ragged_inputs([20, 12, 70, 120], [5, 4, 8, 9], nf, seed=252)
+    B, N = z.shape[:2]
+    g = torch.Generator().manual_seed(253)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+
+    def shuffle(v):                                    # [B, N, ...] rows
+        return torch.stack([v[b][perm[b]] for b in range(B)])
+    em = inp['edge_mask'].view(B, N, N)
+    inp_p = {k: shuffle(v) for k, v in inp.items() if k != 'edge_mask'}
+    inp_p['edge_mask'] = torch.stack([em[b][perm[b]][:, perm[b]] for b in range(B)]).reshape(-1, 1)
+    assert not torch.equal(inp_p['node_mask'], inp['node_mask'])
+    out = P.run_hip_forward(dyn, inp, z, t)
+    out_p = P.run_hip_forward(dyn, inp_p, shuffle(z), t)
+    eh, ev = rel_l2(out_p[..., 3:], shuffle(out)[..., 3:]), rel_l2(out_p[..., :3], shuffle(out)[..., :3])
+    print(f'rows shuffled, team {team}: forward h rel-L2 {eh:.3e} vel {ev:.3e}')
+    assert eh <= 2e-6 and ev <= 1e-5
+    assert float((out_p * (1 - inp_p['node_mask'].float())).abs().max()) == 0.0
+    edm = _edm(dyn, nf, T)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=254)
+    nx, nh = bank.stacked()
+    d = P.dev()
+
+    def chain(i, bx, bh):
+        gi = {k: v.to(d) for k, v in i.items()}
+        return edm.sample_chain(gi['x'], gi['h'], gi['node_mask'], gi['fragment_mask'], gi['linker_mask'], gi['edge_mask'], gi['context'],
+                                keep_frames=2, noise_bank=(bx, bh)).cpu()
+    c = chain(inp, nx, nh)
+    c_p = chain(inp_p, torch.stack([shuffle(nx[k]) for k in range(nx.shape[0])]), torch.stack([shuffle(nh[k]) for k in range(nh.shape[0])]))
+    want = torch.stack([shuffle(c[f]) for f in range(c.shape[0])])
+    ex = rel_l2(c_p[..., :3], want[..., :3])
+    print(f'rows shuffled, team {team}: chain x rel-L2 {ex:.3e}, atom types equal {torch.equal(c_p[0, ..., 3:], want[0, ..., 3:])}')
+    assert ex <= 1e-5 and torch.equal(c_p[0, ..., 3:], want[0, ..., 3:])
