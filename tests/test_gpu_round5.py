@@ -764,3 +764,24 @@ def test_real_atoms_anywhere_among_the_padding_rows(team):
     ex = rel_l2(c_p[..., :3], want[..., :3])
     print(f'rows shuffled, team {team}: chain x rel-L2 {ex:.3e}, atom types equal {torch.equal(c_p[0, ..., 3:], want[0, ..., 3:])}')
     assert ex <= 1e-5 and torch.equal(c_p[0, ..., 3:], want[0, ..., 3:])
+
+
+def test_pocket_atoms_anywhere_among_the_padding_rows():
+    """The same for the radius-graph kernels: fragment, pocket, linker and padding rows in any order."""
+    nf = 9
+    dyn, sd, cfg = P.make_pocket_dynamics(nf, 2, seed=261)
+    inp, z, t = P.pocket_inputs(batch=3, n_frag=12, n_pocket=60, linker=(4, 9), nf=nf, seed=262)
+    B, N = z.shape[:2]
+    g = torch.Generator().manual_seed(263)
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+
+    def shuffle(v):
+        return torch.stack([v[b][perm[b]] for b in range(B)])
+    inp_p = {k: (shuffle(v) if k != 'edge_mask' else v) for k, v in inp.items()}       # edge_mask: the batch id of every row
+    out = P.run_hip_forward(dyn, inp, z, t)
+    out_p = P.run_hip_forward(dyn, inp_p, shuffle(z), t)
+    ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, shuffle(z), inp_p['node_mask'], inp_p['linker_mask'], inp_p['edge_mask'], inp_p['context'])
+    eh, ev, eo = rel_l2(out_p[..., 3:], shuffle(out)[..., 3:]), rel_l2(out_p[..., :3], shuffle(out)[..., :3]), rel_l2(out_p[..., 3:], ref[..., 3:])
+    print(f'pocket rows shuffled: forward h rel-L2 {eh:.3e} vel {ev:.3e}; against the oracle on the shuffled input: h {eo:.3e}')
+    assert eh <= 2e-6 and ev <= 1e-5 and eo <= P.FWD_TOLS['f16x3']
+    assert float((out_p * (1 - inp_p['node_mask'].float())).abs().max()) == 0.0
