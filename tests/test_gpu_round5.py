@@ -785,3 +785,22 @@ def test_pocket_atoms_anywhere_among_the_padding_rows():
     print(f'pocket rows shuffled: forward h rel-L2 {eh:.3e} vel {ev:.3e}; against the oracle on the shuffled input: h {eo:.3e}')
     assert eh <= 2e-6 and ev <= 1e-5 and eo <= P.FWD_TOLS['f16x3']
     assert float((out_p * (1 - inp_p['node_mask'].float())).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('sizes,linkers', [([20, 12], [5, 4]), ([70, 30], [8, 4]), ([120, 12], [9, 4])])
+def test_denoiser_without_context(sizes, linkers):
+    """``context_node_nf = 0``: ``Dynamics.forward(..., context=None)`` appends nothing to the node features (egnn.py:403-407) - one
+    compute unit per molecule, a team, the HBM-resident kernels."""
+    from difflinker_amd import Dynamics
+    nf, L = 8, 2
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=0, hidden_nf=128, n_layers=L, norm_constant=1e-6)
+    sd = seeded_state_dict(nf + 1, 128, L, 271)
+    dyn.load_state_dict(sd, strict=True)
+    dyn = dyn.to(P.dev())
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=0, n_layers=L)
+    inp, z, t = P.ragged_inputs(sizes, linkers, nf, seed=272)
+    ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], None)
+    d = P.dev()
+    out = dyn.forward(t.to(d), z.to(d), inp['node_mask'].to(d), inp['linker_mask'].to(d), inp['edge_mask'].to(d), None).cpu()
+    ev, eh = P.report(f'no context, {sizes[0]} atoms', out, ref, z)
+    assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
