@@ -804,3 +804,35 @@ def test_denoiser_without_context(sizes, linkers):
     out = dyn.forward(t.to(d), z.to(d), inp['node_mask'].to(d), inp['linker_mask'].to(d), inp['edge_mask'].to(d), None).cpu()
     ev, eh = P.report(f'no context, {sizes[0]} atoms', out, ref, z)
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+
+
+@pytest.mark.parametrize('norm_constant,normalization_factor', [(0.0, 100.0), (1.0, 100.0), (1e-6, 1.0), (0.5, 10.0)])
+def test_other_norm_constants_and_normalization_factors(norm_constant, normalization_factor):
+    """Every released configuration has ``norm_constant = 1e-6``, ``normalization_factor = 100``; the class defaults are 0 and 100
+    (egnn.py:324-329) and both are free hyper-parameters: the coordinate difference is divided by ``norm + norm_constant``
+    (egnn.py:240-247), message and coordinate sums by ``normalization_factor`` (egnn.py:294-301) - FC on one compute unit, a team
+    and the HBM-resident kernels, and the radius-graph kernels."""
+    from difflinker_amd import Dynamics, DynamicsWithPockets
+    nf, L = 8, 2
+    for sizes, linkers in (([20, 12], [5, 4]), ([70, 30], [8, 4]), ([120, 12], [9, 4])):
+        dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=1, hidden_nf=128, n_layers=L, norm_constant=norm_constant,
+                       normalization_factor=normalization_factor)
+        sd = seeded_state_dict(nf + 2, 128, L, 281, coord_gain=1.0 if normalization_factor == 100.0 else 0.02)
+        dyn.load_state_dict(sd, strict=True)
+        cfg = EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=L, norm_constant=norm_constant, normalization_factor=normalization_factor)
+        inp, z, t = P.ragged_inputs(sizes, linkers, nf, seed=282)
+        ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        out = P.run_hip_forward(dyn.to(P.dev()), inp, z, t)
+        ev, eh = P.report(f'norm_constant {norm_constant:g}, normalization_factor {normalization_factor:g}, {sizes[0]} atoms', out, ref, z)
+        assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+    pdyn = DynamicsWithPockets(n_dims=3, in_node_nf=nf, context_node_nf=2, hidden_nf=128, n_layers=L, norm_constant=norm_constant,
+                               normalization_factor=normalization_factor, graph_type='FC-10A-4A')
+    sd = seeded_state_dict(nf + 3, 128, L, 283, coord_gain=0.02)
+    pdyn.load_state_dict(sd, strict=True)
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=2, n_layers=L, norm_constant=norm_constant, normalization_factor=normalization_factor,
+                     graph_type='FC-10A-4A')
+    inp, z, t = P.pocket_inputs(batch=2, n_frag=12, n_pocket=60, linker=(4, 8), nf=nf, seed=284)
+    ref = egnn_oracle.dynamics_forward_pockets(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+    out = P.run_hip_forward(pdyn.to(P.dev()), inp, z, t)
+    ev, eh = P.report(f'pockets, norm_constant {norm_constant:g}, normalization_factor {normalization_factor:g}', out, ref, z)
+    assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
