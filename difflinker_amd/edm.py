@@ -645,6 +645,11 @@ class EDM(torch.nn.Module):
                 ev1.record(cur)
                 self.last_kernel_events = (ev0, ev1)
         self._raise_on_chain_flags(flags, steps)
+        bias = float(self.norm_biases[1])
+        if bias != 0.0 and keep_frames > 1:
+            # the kernel writes the rows of real atoms; the reference's intermediate frames are unnormalize_z of the WHOLE z
+            # (edm.py:357-361), whose padding rows - zeros - come out as the feature bias (no released configuration has one)
+            chain[1:, :, :, self.n_dims:] += bias * (1.0 - node_mask.to(chain.dtype).reshape(bs, n, 1))
         return chain
 
     def philox_noise_bank(self, n_samples, n_nodes, device, mol_offset=0, seed=None, n_draws=None):

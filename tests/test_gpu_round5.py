@@ -836,3 +836,41 @@ def test_other_norm_constants_and_normalization_factors(norm_constant, normaliza
     out = P.run_hip_forward(pdyn.to(P.dev()), inp, z, t)
     ev, eh = P.report(f'pockets, norm_constant {norm_constant:g}, normalization_factor {normalization_factor:g}', out, ref, z)
     assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+
+
+@pytest.mark.parametrize('kind', ['EDM', 'EDM on teams', 'InpaintingEDM'])
+def test_sampler_with_other_schedule_and_normalisation(kind):
+    """Every released configuration samples with polynomial_2 / 1e-5 / norm_values [1, 4, 10] / no bias; the sampler takes any
+    ``polynomial_<p>`` schedule, precision, ``timesteps``, ``norm_values`` and ``norm_biases`` (edm.py:24-60, 347-361): here
+    polynomial_3, 1e-4, a 200-step table sampled in 9 steps, x / 2, (h - 0.5) / 3."""
+    from difflinker_amd import Dynamics, EDM, InpaintingEDM
+    nf, L, T = 8, 2, 9
+    inpaint = kind == 'InpaintingEDM'
+    sizes, linkers = ([60, 20], [8, 4]) if kind == 'EDM on teams' else ([20, 12, 33], [5, 4, 7])
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=1, hidden_nf=128, n_layers=L, norm_constant=1e-6, centering=inpaint)
+    sd = seeded_state_dict(nf + 2, 128, L, 291)
+    dyn.load_state_dict(sd, strict=True)
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=1, n_layers=L, centering=inpaint)
+    kw = dict(in_node_nf=nf, timesteps=200, noise_schedule='polynomial_3', noise_precision=1e-4, norm_values=(2., 3., 5.), norm_biases=(None, 0.5, 0.))
+    edm = (InpaintingEDM if inpaint else EDM)(dyn.to(P.dev()), n_dims=3, loss_type='l2', **kw).to(P.dev())
+    edm.T = T
+    inp, _, _ = P.ragged_inputs(sizes, linkers, nf, seed=292)
+    B, N = inp['x'].shape[:2]
+    bank = edm_oracle.NoiseBank.generate(2 * T + 1 if inpaint else T, B, N, 3, nf, seed=293)
+    orc = (edm_oracle.InpaintingEDMOracle if inpaint else edm_oracle.EDMOracle)(edm_oracle.make_dynamics_oracle(sd, cfg), **kw)
+    orc.T = T
+    g = {k: v.to(P.dev()) for k, v in inp.items()}
+    if inpaint:
+        want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['edge_mask'], inp['fragment_mask'], inp['linker_mask'], inp['context'],
+                                bank, keep_frames=3)
+        got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['edge_mask'], g['fragment_mask'], g['linker_mask'], g['context'],
+                               keep_frames=3, noise_bank=bank.stacked()).cpu()
+        ex, efr = rel_l2(got[0, ..., :3], want[0, ..., :3]), rel_l2(got[1:], want[1:])
+        print(f'[{kind}, polynomial_3 / 1e-4 / 200 steps / norm (2, 3) bias 0.5] x rel-L2 {ex:.3e} frames {efr:.3e}')
+        assert ex <= P.CHAIN_TOL and efr <= P.CHAIN_TOL and torch.equal(got[0, ..., 3:], want[0, ..., 3:])
+    else:
+        want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'],
+                                bank, keep_frames=3)
+        got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
+                               keep_frames=3, noise_bank=bank.stacked()).cpu()
+        P.check_chain(f'{kind}, polynomial_3 / 1e-4 / 200 steps / norm (2, 3) bias 0.5', got, want, inp)

@@ -167,15 +167,17 @@ def test_same_seed_same_init_as_reference():
         assert torch.equal(a[k], b[k]), k
 
 
-def test_step_coefficients_match_oracle_scalars():
+@pytest.mark.parametrize('timesteps,schedule,precision', [(500, 'polynomial_2', 1e-5), (1000, 'polynomial_2', 1e-5), (200, 'polynomial_3', 1e-4),
+                                                          (100, 'polynomial_1', 1e-3)])
+def test_step_coefficients_match_oracle_scalars(timesteps, schedule, precision):
     from difflinker_amd import Dynamics, EDM
     dyn = Dynamics(3, 8, 1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
-    for T in (500, 50, 12):
-        edm = EDM(dyn, in_node_nf=8, n_dims=3, timesteps=500, noise_schedule='polynomial_2', noise_precision=1e-5,
+    for T in (timesteps, 50, 12):
+        edm = EDM(dyn, in_node_nf=8, n_dims=3, timesteps=timesteps, noise_schedule=schedule, noise_precision=precision,
                   loss_type='l2', norm_values=[1, 4, 10])
         edm.T = T
         coefs, (inv_a0, s0, sx) = edm.step_coefficients()
-        orc = edm_oracle.EDMOracle(None, in_node_nf=8, timesteps=500)
+        orc = edm_oracle.EDMOracle(None, in_node_nf=8, timesteps=timesteps, noise_schedule=schedule, noise_precision=precision)
         orc.T = T
         assert torch.equal(edm.gamma.gamma.data, orc.gamma_table)
         z = torch.zeros(1, 1, 1)
