@@ -874,3 +874,47 @@ def test_sampler_with_other_schedule_and_normalisation(kind):
         got = edm.sample_chain(g['x'], g['h'], g['node_mask'], g['fragment_mask'], g['linker_mask'], g['edge_mask'], g['context'],
                                keep_frames=3, noise_bank=bank.stacked()).cpu()
         P.check_chain(f'{kind}, polynomial_3 / 1e-4 / 200 steps / norm (2, 3) bias 0.5', got, want, inp)
+
+
+@pytest.mark.parametrize('nf,ctx', [(10, 3), (13, 2), (1, 0), (4, 4)])
+def test_other_feature_and_context_widths(nf, ctx):
+    """``in_node_nf`` is the number of atom types (+ 1 with ``--include_charges``: train_difflinker.py:51-52), the context up to
+    anchors + fragment + pocket masks: 8..10 and 1..3 in practice; the C ABI takes 3 + nf <= 16, context <= 4,
+    nf + time + context <= 16.  Forward on one compute unit per molecule, a team and the HBM-resident kernels, then a short chain."""
+    from difflinker_amd import Dynamics
+    L, T = 2, 5
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=ctx, hidden_nf=128, n_layers=L, norm_constant=1e-6)
+    sd = seeded_state_dict(nf + ctx + 1, 128, L, 300 + nf, coord_gain=1.0)      # (a velocity of the order of the coordinates: above its ulp(|x|) floor)
+    dyn.load_state_dict(sd, strict=True)
+    dyn = dyn.to(P.dev())
+    cfg = EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L)
+    g = torch.Generator().manual_seed(301)
+    d = P.dev()
+
+    def with_context(inp):
+        B, N = inp['x'].shape[:2]
+        inp['context'] = (torch.randn(B, N, ctx, generator=g) * inp['node_mask'].float()) if ctx else None
+        return inp
+    for sizes, linkers in (([20, 12], [5, 4]), ([70, 30], [8, 4]), ([120, 12], [9, 4])):
+        inp, z, t = P.ragged_inputs(sizes, linkers, nf, seed=302)
+        inp = with_context(inp)
+        ref = egnn_oracle.dynamics_forward(sd, cfg, t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
+        out = dyn.forward(t.to(d), z.to(d), inp['node_mask'].to(d), inp['linker_mask'].to(d), inp['edge_mask'].to(d),
+                          inp['context'].to(d) if ctx else None).cpu()
+        ev, eh = P.report(f'nf {nf}, context {ctx}, {sizes[0]} atoms', out, ref, z)
+        assert ev <= P.FWD_TOLS['f16x3'] and eh <= P.FWD_TOLS['f16x3']
+    inp, _, _ = P.ragged_inputs([20, 41, 60], [4, 7, 6], nf, seed=303)
+    inp = with_context(inp)
+    B, N = inp['x'].shape[:2]
+    sd = seeded_state_dict(nf + ctx + 1, 128, L, 300 + nf)                      # (the chain: small steps)
+    dyn.load_state_dict(sd, strict=True)
+    dyn.invalidate_packed()
+    edm = _edm(dyn, nf, T)
+    bank = edm_oracle.NoiseBank.generate(T, B, N, 3, nf, seed=304)
+    orc = edm_oracle.EDMOracle(edm_oracle.make_dynamics_oracle(sd, cfg), in_node_nf=nf, timesteps=500)
+    orc.T = T
+    want = orc.sample_chain(inp['x'], inp['h'], inp['node_mask'], inp['fragment_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'],
+                            bank, keep_frames=2)
+    got = edm.sample_chain(inp['x'].to(d), inp['h'].to(d), inp['node_mask'].to(d), inp['fragment_mask'].to(d), inp['linker_mask'].to(d),
+                           inp['edge_mask'].to(d), inp['context'].to(d) if ctx else None, keep_frames=2, noise_bank=bank.stacked()).cpu()
+    P.check_chain(f'chain, nf {nf}, context {ctx}', got, want, inp)
