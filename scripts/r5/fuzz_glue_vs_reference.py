@@ -74,12 +74,56 @@ def same(a, b, where, bad):
             bad.append(f'{where}[{k}] differs')
 
 
+def schedules_and_step_scalars(n, bad):
+    """The product's ``PredefinedNoiseSchedule`` (tables and lookups) and the per-step scalars its sampler kernels are given
+    (``EDM.step_coefficients``) against the reference's ``src/noise.py`` and the expressions of ``EDM.sample_p_zs_given_zt_only_linker`` /
+    ``sample_p_xh_given_z0_only_linker`` (src/edm.py:178-242) evaluated by the reference's own methods - bit for bit."""
+    from src.noise import PredefinedNoiseSchedule as RefSchedule
+    from src.edm import EDM as RefEDM
+    from difflinker_amd.noise import PredefinedNoiseSchedule as OurSchedule
+    from difflinker_amd import EDM as OurEDM, Dynamics as OurDynamics
+    rng = np.random.default_rng(77)
+    dyn = OurDynamics(3, 8, 1, hidden_nf=128, n_layers=1, norm_constant=1e-6)
+    for _ in range(n):
+        timesteps = int(rng.integers(2, 1501))
+        sched = str(rng.choice(['polynomial_1', 'polynomial_2', 'polynomial_3', 'polynomial_2.5', 'cosine']))
+        prec = float(rng.choice([1e-5, 1e-4, 1e-3]))
+        r, o = RefSchedule(sched, timesteps=timesteps, precision=prec), OurSchedule(sched, timesteps=timesteps, precision=prec)
+        t = torch.rand(5, 1)
+        if not (torch.equal(r.gamma.data, o.gamma.data) and torch.equal(r(t), o(t))):
+            bad.append(f'noise schedule {sched} timesteps={timesteps} precision={prec}')
+        if sched == 'cosine':
+            continue
+        T = int(rng.integers(1, min(timesteps, 40) + 1))
+        kw = dict(in_node_nf=8, n_dims=3, timesteps=timesteps, noise_schedule=sched, noise_precision=prec, loss_type='l2', norm_values=[1, 4, 10])
+        ours, ref = OurEDM(dyn, **kw), RefEDM(dynamics=torch.nn.Identity(), **kw)
+        ours.T = ref.T = T
+        coefs, (inv_a0, s0, sx) = ours.step_coefficients()
+        z = torch.zeros(1, 1, 1)
+        for q, s_ in enumerate(reversed(range(T))):
+            s_arr, t_arr = torch.full((1, 1), s_) / T, (torch.full((1, 1), s_) + 1) / T
+            g_s, g_t = ref.gamma(s_arr), ref.gamma(t_arr)
+            s2, s_ts, a_ts = ref.sigma_and_alpha_t_given_s(g_t, g_s, z)
+            want = torch.stack([t_arr.view(()), a_ts.view(()), (s2 / a_ts / ref.sigma(g_t, z)).view(()),
+                                (s_ts * ref.sigma(g_s, z) / ref.sigma(g_t, z)).view(())])
+            if not torch.equal(coefs[q], want):
+                bad.append(f'step scalars {sched} timesteps={timesteps} precision={prec} T={T} step {q}: {coefs[q].tolist()} != {want.tolist()}')
+                break
+        g0 = ref.gamma(torch.zeros(1, 1))
+        if not (abs(sx - float(torch.exp(0.5 * g0))) < 1e-9 and abs(inv_a0 - float(1. / ref.alpha(g0, z))) < 1e-7 and abs(s0 - float(ref.sigma(g0, z))) < 1e-9):
+            bad.append(f'decode scalars {sched} timesteps={timesteps} precision={prec}')
+    return n
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=200)
     ap.add_argument('--seed', type=int, default=0)
     a = ap.parse_args()
     t0, bad, chains, worst, glue = time.time(), [], 0, 0.0, 0
+    n_sched = schedules_and_step_scalars(200, bad)
+    print(f'{n_sched} noise schedules (polynomial_1 / 2 / 2.5 / 3, cosine; 2..1500 steps; precisions) and the per-step scalars of chains of 1..40 steps: '
+          f'{len(bad)} differences from the reference', flush=True)
     for k in range(a.cases):
         seed = a.seed * 100000 + k
         rng = np.random.default_rng(seed)
