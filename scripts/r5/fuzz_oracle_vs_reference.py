@@ -164,12 +164,60 @@ def run(c):
     return compare(reference, oracle)
 
 
+@torch.no_grad()
+def size_predictor(n, bad):
+    """oracle/size_oracle.py against the unmodified ``SizeGNN`` (src/linker_size.py:45-91) driven as ``SizeClassifier.forward`` drives it
+    at inference (src/linker_size_lightning.py:83-110; tests/golden/make_golden.py::size_gnn restates those ten lines)."""
+    from src.linker_size import SizeGNN
+    from src.egnn import coord2diff
+    from difflinker_amd.datasets import collate_with_fragment_edges
+    from helpers import seeded_size_state_dict
+    from oracle import size_oracle
+    rng = np.random.default_rng(99)
+    worst = 0.0
+    for k in range(n):
+        in_nf, out_nf, L, bn = int(rng.choice([8, 9, 10])), int(rng.integers(2, 40)), int(rng.integers(1, 5)), bool(rng.random() < 0.4)
+        g = torch.Generator().manual_seed(1000 + k)
+        mols = []
+        for _ in range(int(rng.integers(1, 6))):
+            frag_n, link = int(rng.integers(0, 40)), int(rng.integers(1, 8))
+            nn_ = frag_n + link
+            frag = torch.zeros(nn_)
+            frag[:frag_n] = 1
+            types = torch.randint(0, in_nf, (nn_,), generator=g)
+            mols.append({'positions': float(rng.choice([0.5, 1.2, 1.6, 3.0])) * torch.randn((nn_, 3), generator=g),
+                         'one_hot': torch.nn.functional.one_hot(types, in_nf).float(), 'anchors': torch.zeros(nn_), 'fragment_mask': frag,
+                         'linker_mask': 1 - frag, 'num_atoms': nn_, 'uuid': 0, 'name': 'm'})
+        data = collate_with_fragment_edges(mols)
+        sd = seeded_size_state_dict(in_nf, 128, out_nf, L, seed=2000 + k, batch_norm=bn)
+        gnn = SizeGNN(in_node_nf=in_nf, hidden_nf=128, out_node_nf=out_nf, n_layers=L, normalization='batch_norm' if bn else None)
+        gnn.load_state_dict(sd, strict=True)
+        gnn.eval()
+        fragment_mask, edge_mask, edges = data['fragment_mask'], data['edge_mask'], data['edges']
+        x, h = data['positions'] * fragment_mask, data['one_hot'] * fragment_mask
+        bs, nn_ = x.shape[0], x.shape[1]
+        distances, _ = coord2diff(x.view(bs * nn_, -1), edges)
+        dmask = (edge_mask.bool() & (distances < 6)).long()
+        want = gnn.forward(h.view(bs * nn_, -1), edges, distances, fragment_mask.view(bs * nn_, 1), dmask).view(bs, nn_, -1).mean(1)
+        got = size_oracle.size_classifier_logits(sd, data['one_hot'], data['positions'], data['fragment_mask'], data['edge_mask'], L,
+                                                 batch_norm=bn, pre='')
+        e = max_abs(got, want)
+        worst = max(worst, e)
+        if e > 1e-6 * max(1.0, float(want.abs().max())):
+            bad.append(f'size predictor case {k}: max-abs {e:.2e}')
+    return worst
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--cases', type=int, default=300)
     ap.add_argument('--seed', type=int, default=0)
     a = ap.parse_args()
     t0, worst, bad, kinds, nans = time.time(), {}, [], {}, 0
+    if a.seed == 0:
+        w = size_predictor(200, bad)
+        print(f'linker-size predictor: 200 random cases (8..10 atom types, 2..39 classes, 1..4 layers, with / without BatchNorm), largest difference from the '
+              f"reference's SizeGNN {w:.1e}, {len(bad)} failures", flush=True)
     for k in range(a.cases):
         c = draw(a.seed * 100000 + k)
         tag = ' '.join(f'{key}={c[key]}' for key in ('kind', 'nf', 'ctx', 'L', 'sub', 'hidden', 'attention', 'tanh', 'aggregation_method', 'sin_embedding',
