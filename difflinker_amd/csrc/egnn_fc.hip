@@ -1381,10 +1381,18 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
         // atom - for the rest of the launch - and the sums are formed and multiplied by the mask as the reference does.
         const float phi = cload(sc, ES_W7L1) * fmaf(cload(sc, ES_L1_W6), u1b, cload(sc, ES_B6));
         const bool proven = 2.0f * float(nb) * phi < 1e37f;
-        if (!proven && ctx_i(v, MS_FULL) == 0) {
-            const int tid_ = q.tid;
-            receivers_all(v, TEAM ? ctx_i(v, TM_NOWN) : nb, tid_);
+        // (`proven` is workgroup-uniform: every input is a scalar of the packed model or an LDS bound that the barrier ending
+        // open_pass published.  MS_FULL is WRITTEN inside the branch below, so every wave reads it before anybody may write it -
+        // a wave that saw the new value would skip the branch and its barrier, and the pair loop would start on a half-built
+        // receiver list: ADVICE round 5.  The extra barrier exists on the unproven path only)
+        if (!proven) {
+            const bool widen = ctx_i(v, MS_FULL) == 0;
             __syncthreads();
+            if (widen) {
+                const int tid_ = q.tid;
+                receivers_all(v, TEAM ? ctx_i(v, TM_NOWN) : nb, tid_);
+                __syncthreads();
+            }
         }
     }
     pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,

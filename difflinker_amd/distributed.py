@@ -5,10 +5,12 @@ process group's backend is ``nccl``; ``gloo`` in the CPU tests).
 
 One process per GPU (``torch.distributed``); rank r takes a contiguous slice of the collated
 batch.  Noise comes from the in-kernel counter-based generator keyed by the GLOBAL molecule index
-(or from an explicit global bank, sliced), so the sample of molecule b does not depend on the world size - bit for bit with one
-launch per chain (``edm.split_chain = False``, ``edm.overflow_teams = False``); with the default two-launch chain of a ragged
-shard that fills its GPU (``EDM.split_chain``: the big molecules finish on teams of two, whose summation order differs) to fp32
-rounding, ~1e-8 on the final coordinates.
+(or from an explicit global bank, sliced), so the sample of molecule b does not depend on the world size - bit for bit, with
+default settings (round 6): a shard pins ``EDM.coef_batch`` / ``EDM.team_batch`` to the whole batch, which also keeps its chain
+in ONE launch on one compute unit per molecule - the two-launch hand-over of ``EDM.split_chain`` and the surplus teams of
+``EDM.overflow_teams`` follow the sizes of the molecules at hand and are for unsharded batches only (they change the order in
+which a molecule's messages are summed: ~1e-8 on the final coordinates).  The unsharded call of a batch BEYOND one GPU's compute
+units runs one launch per chain too, so world = 1 / 2 / 4 / 8 sample the same bits (tests/test_gpu_round6.py, C3 shape).
 """
 import time
 
@@ -48,9 +50,11 @@ def shard_sampler_inputs(inputs, rank, world_size):
 def all_gather_frames(local_chain, batch_size, group=None):
     """All-gather per-rank chains ``[K, B_r, N, D]`` into ``[K, B, N, D]`` (rank order = batch order).
     Shards may differ by one molecule: they are padded to the largest shard for the collective."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
+    if not dist.is_initialized():
         return local_chain
+    # (a process group of ONE rank still goes through the collective: the RCCL branch below then runs - and is tested - on a
+    # single-GPU box; a job without a process group, bench.py --gpus 1, returns above)
+    world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     sizes = [shard_bounds(batch_size, r, world) for r in range(world)]
     bmax = max(hi - lo for lo, hi in sizes)

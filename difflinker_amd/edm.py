@@ -20,6 +20,7 @@ Out of scope (training only): ``EDM.forward`` and the likelihood/KL terms (edm.p
 """
 import ctypes
 import os
+import threading
 import warnings
 
 import numpy as np
@@ -59,6 +60,8 @@ def forward_cost(n, n_linker, n_layers, sublayers, team=1):
 
 
 _PLAN_CACHE = {}
+_CACHE_LOCK = threading.Lock()           # the plan cache, the side streams and their workspaces are shared by every EDM of the process
+_SPLIT_QSCALE = os.environ.get('DIFFLINKER_SPLIT_QSCALE', '1.0')          # (calibration experiments: scripts/r5/ab_split_qscale.sh)
 
 
 def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_gain=0.02, grid=48, allow_singles=None):
@@ -77,10 +80,10 @@ def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_
     if B > compute_units or B == 0:
         return None
     allow_singles = bool(allow_singles)
-    key = (tuple(sizes), tuple(linkers), n_calls, compute_units, n_layers, sublayers, min_gain, grid, bool(allow_singles),
-           os.environ.get('DIFFLINKER_SPLIT_QSCALE', '1.0'))
-    if key in _PLAN_CACHE:
-        return _PLAN_CACHE[key]
+    key = (tuple(sizes), tuple(linkers), n_calls, compute_units, n_layers, sublayers, min_gain, grid, bool(allow_singles), _SPLIT_QSCALE)
+    with _CACHE_LOCK:
+        if key in _PLAN_CACHE:
+            return _PLAN_CACHE[key]
     table = {}
     for n, l in set(zip(sizes, linkers)):
         table[(n, l)] = (forward_cost(n, l, n_layers, sublayers, 1), forward_cost(n, l, n_layers, sublayers, 2))
@@ -107,13 +110,14 @@ def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_
         if best is None or total < best[0]:
             best = (total, q_end.tolist(), teams.tolist(), singles.tolist())
     plan = None if best is None or best[0] > (1.0 - min_gain) * single else (best[1], best[2], best[3])
-    qscale = float(os.environ.get('DIFFLINKER_SPLIT_QSCALE', '1.0'))          # (calibration experiments: scripts/r5/ab_split_qscale.sh)
+    qscale = float(_SPLIT_QSCALE)
     if plan is not None and qscale != 1.0:
         stop = set(plan[1]) | set(plan[2])
         plan = ([max(1, min(n_calls - 1, int(round(q * qscale)))) if b in stop else q for b, q in enumerate(plan[0])], plan[1], plan[2])
-    if len(_PLAN_CACHE) > 64:
-        _PLAN_CACHE.clear()
-    _PLAN_CACHE[key] = plan
+    with _CACHE_LOCK:
+        if len(_PLAN_CACHE) > 64:
+            _PLAN_CACHE.clear()
+        _PLAN_CACHE[key] = plan
     return plan
 
 
@@ -176,9 +180,19 @@ class EDM(torch.nn.Module):
     @staticmethod
     def _side_stream(dev):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
-        if key not in _SIDE_STREAMS:
-            _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
-        return _SIDE_STREAMS[key]
+        with _CACHE_LOCK:
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+            return _SIDE_STREAMS[key]
+
+    @staticmethod
+    def _side_workspace(key, need, dev):
+        """scratch of a launch beside the main one, one buffer per (device, role): grown, never shrunk, reused by every chain"""
+        with _CACHE_LOCK:
+            ws = _SIDE_WORKSPACE.get(key)
+            if ws is None or ws.numel() < need:
+                ws = _SIDE_WORKSPACE[key] = torch.empty(need, dtype=torch.uint8, device=dev)
+            return ws
 
     def forward(self, *args, **kwargs):
         raise NotImplementedError('EDM.forward is the training loss (edm.py:41-124): out of scope of the '
@@ -431,7 +445,9 @@ class EDM(torch.nn.Module):
             self.coef_batch = bs
         if pinned_team is None:
             # the team sizes of every part follow the size of the WHOLE batch, exactly as in a shard of it
-            # (distributed.sample_chain_sharded pins the same number): world = 1 and world > 1 sample the same bits
+            # (distributed.sample_chain_sharded pins the same number; a pinned EDM.team_batch also keeps the chain in ONE launch
+            # - no split_plan, no surplus teams): world = 1 and world > 1 sample the same bits for every molecule that the
+            # unsharded call runs in one launch as well (a batch beyond the number of compute units, or split_chain = False)
             self.team_batch = bs
         try:
             chain = torch.zeros((keep_frames, bs, n, self.n_dims + self.in_node_nf), device=dev)
@@ -448,12 +464,12 @@ class EDM(torch.nn.Module):
             # every part reports NaNs in ITS numbering, for ITS first offending denoiser call; the reference raises at the first
             # call whose output holds a NaN with the molecules that are NaN THERE (egnn.py:441-442) and its callers index the batch
             # with the sets of the exception (lightning.py:353-361): collect the sets in whole-batch numbering with their call
-            # index, keep those of the earliest call, raise once.  A part that failed at call 0 ends the search: nothing is earlier.
+            # index, keep those of the earliest call, raise once.  Every part runs even after one has failed at call 0: the
+            # molecules of another part that are NaN at call 0 too belong to the sets the reference reports (the
+            # exception is rare and its callers re-sample the batch anyway, generate.py:154-161)
             nan_sets = []
 
             def run_part(idx, fn):
-                if any(step == 0 for step, _ in nan_sets):
-                    return None
                 try:
                     return fn()
                 except utils.FoundNaNException as e:
@@ -508,7 +524,8 @@ class EDM(torch.nn.Module):
         ctx = f32(context, (bs, n, self.dynamics.context_node_nf)) if context is not None else None
         # longest-processing-time order: a molecule holds one compute unit for the whole chain and a workgroup's cost grows
         # with n_b^2, so the big ones are launched first (matters once the batch exceeds the number of compute units)
-        order = torch.argsort(nm.ne(0).sum(1), descending=True, stable=True).to(torch.int32).contiguous()
+        n_real = nm.ne(0).sum(1)
+        order = torch.argsort(n_real, descending=True, stable=True).to(torch.int32).contiguous()
         chain = torch.zeros((keep_frames, bs, n, self.n_dims + nf), device=dev)
         flags = torch.zeros(bs, dtype=torch.int32, device=dev)
         steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
@@ -526,6 +543,13 @@ class EDM(torch.nn.Module):
             cus = torch.cuda.get_device_properties(dev).multi_processor_count
             if cus < bs <= cus + cus // 4:
                 over = bs - cus
+                team2 = 4 if over <= cus // 16 else 2
+                # (the entry point refuses a team the device cannot hold at once - its round-up to whole groups of eight molecules
+                # may not fit when the number of compute units is no multiple of 16: then everybody keeps one compute unit)
+                while team2 > 1 and int(lib.dl_team_max(over)) < team2:
+                    team2 //= 2
+                if team2 < 2:
+                    over = 0
             elif cus < bs < 2 * cus and not getattr(EDM, '_warned_off_sweet_spot', False):
                 EDM._warned_off_sweet_spot = True              # say so once
                 warnings.warn(f'EDM.sample_chain: a batch of {bs} molecules on {cus} compute units runs one molecule per compute unit '
@@ -535,12 +559,18 @@ class EDM(torch.nn.Module):
         ws, ws_bytes = self.dynamics.workspace(bs - over, team, dev)
 
         # the static hand-over inside a ragged batch that fills the chip (split_plan): two launches
+        # (not for a shard of a batch - EDM.team_batch pinned, distributed.sample_chain_sharded: the plan follows the sizes of the
+        # molecules at hand, and a molecule's sample must not depend on how its batch was split - SURVEY 8e)
         plan = None
-        if team == 1 and over == 0 and self.split_chain and not self.dynamics._no_teams and bs <= compute_units(dev) and T >= 20:
-            sizes_h = nm.ne(0).sum(1).cpu().tolist()
+        if team == 1 and over == 0 and self.split_chain and self.team_batch is None and not self.dynamics._no_teams \
+                and bs <= compute_units(dev) and T >= 20:
+            counts = torch.stack([n_real, lm.ne(0).sum(1)]).cpu()             # ONE device-to-host copy: sizes and linker sizes
+            sizes_h, linkers_h = counts[0].tolist(), counts[1].tolist()
             if max(sizes_h) <= int(lib.dl_max_atoms()) and min(sizes_h) > 0:
-                plan = split_plan(sizes_h, lm.ne(0).sum(1).cpu().tolist(), T + 1, compute_units(dev), self.dynamics.n_layers,
+                plan = split_plan(sizes_h, linkers_h, T + 1, compute_units(dev), self.dynamics.n_layers,
                                   int(getattr(self.dynamics, 'inv_sublayers', 2)), allow_singles=bool(self.split_singles))
+                if plan is not None and plan[1] and int(lib.dl_team_max(len(plan[1]))) < 2:
+                    plan = None                                               # the teams of the second phase would not fit at once
         q_end_t = z_state = None
         if plan is not None:
             q_end_t = torch.tensor(plan[0], dtype=torch.int32, device=dev)
@@ -571,13 +601,10 @@ class EDM(torch.nn.Module):
             if over:
                 # (its own flag arrays: the team entry point clears them on its stream; its own workspace: the launches overlap)
                 side = self._side_stream(dev)
-                team2 = 4 if over <= cus // 16 else 2
                 flags2 = torch.zeros(bs, dtype=torch.int32, device=dev)
                 steps2 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
                 need2 = int(lib.dl_workspace_bytes(over, team2))
-                ws2 = _SIDE_WORKSPACE.get(side)
-                if ws2 is None or ws2.numel() < need2:
-                    ws2 = _SIDE_WORKSPACE[side] = torch.empty(need2, dtype=torch.uint8, device=dev)
+                ws2 = self._side_workspace((dev.index, 'teams'), need2, dev)
                 args2 = chain_args(flags2, steps2, team2, ws2, need2, bs - over, over)
                 ready = torch.cuda.Event()
                 ready.record(cur)                          # inputs, coefficients, noise bank: enqueued on the current stream
@@ -610,9 +637,7 @@ class EDM(torch.nn.Module):
                     flags2 = torch.zeros(bs, dtype=torch.int32, device=dev)
                     steps2 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
                     need2 = int(lib.dl_workspace_bytes(m2, 2))
-                    ws2 = _SIDE_WORKSPACE.get(side)
-                    if ws2 is None or ws2.numel() < need2:
-                        ws2 = _SIDE_WORKSPACE[side] = torch.empty(need2, dtype=torch.uint8, device=dev)
+                    ws2 = self._side_workspace((dev.index, 'teams'), need2, dev)
                     args2 = chain_args(flags2, steps2, 2, ws2, need2, 0, m2, q_begin=q_end_t, skip=flags, order_=rest)
                     side.wait_event(after_first)
                     _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args2), ctypes.c_void_p(side.cuda_stream)),
@@ -625,9 +650,7 @@ class EDM(torch.nn.Module):
                     flags3 = torch.zeros(bs, dtype=torch.int32, device=dev)
                     steps3 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
                     need3 = int(lib.dl_workspace_bytes(m1, 1))
-                    ws3 = _SIDE_WORKSPACE.get(cur)
-                    if ws3 is None or ws3.numel() < need3:
-                        ws3 = _SIDE_WORKSPACE[cur] = torch.empty(need3, dtype=torch.uint8, device=dev)
+                    ws3 = self._side_workspace((dev.index, 'singles'), need3, dev)
                     args3 = chain_args(flags3, steps3, 1, ws3, need3, 0, m1, q_begin=q_end_t, skip=flags, order_=rest1)
                     _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args3), ctypes.c_void_p(cur.cuda_stream)),
                                'dl_sample_chain_fc (second phase of a split chain: one compute unit each)')

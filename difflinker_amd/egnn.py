@@ -13,6 +13,7 @@ the HIP path raise.
 """
 import ctypes
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -518,6 +519,10 @@ class Dynamics(nn.Module):
         try:
             return fn()
         except TeamNotAssembled:
+            # (said once per occurrence: the re-run doubles the cost of the call - ADVICE round 5)
+            warnings.warn('a team of workgroups did not assemble in time (another kernel held compute units, or a launch queued behind '
+                          'a long one outlived the bounded wait): the call is re-run with one compute unit per molecule, from the same '
+                          'draws', RuntimeWarning, stacklevel=2)
             saved, self._no_teams = self._no_teams, True
             try:
                 return fn()

@@ -138,7 +138,12 @@ int32_t dl_max_atoms(void);
  *               (EquivariantUpdate, :101-125) is evaluated only for receiving atoms with linker_mask != 0: the
  *               reference multiplies every other atom's sum by zero (:113-116), so the outputs are the same
  *   edge_mask   device int8 [B,N,N] ({0,-1,-2} from collate; multiplies every message as-is) or NULL
- *               contract: edge_mask must be 0 wherever an endpoint has node_mask 0 (datasets.py:366-369)
+ *               contract: edge_mask must be 0 wherever an endpoint has node_mask 0 (datasets.py:366-369).  A zero byte
+ *               BETWEEN TWO REAL ATOMS (collate never writes one: every real pair is -1, the diagonal -2) removes that
+ *               message like the reference's `* edge_mask` does, exactly in DL_PRECISION_FP32 and in the coordinate head of
+ *               every mode; the f16 modes' GCL messages fold the mask into the SiLU reciprocal and apply such a byte as a
+ *               factor 2^-100 instead of 0 - below one ulp of any fp32 sum while the message's pre-activation stays under
+ *               the f16-range limit of bit4 below (2^75): not observable, but not bit-zero either
  *   context     device f32 [B,N,ctx] or NULL when ctx == 0
  *   out         device [B,N,3+nf]   eps_hat = cat[vel, h_final]; padded rows are written as 0
  *   nan_flags   device int32 [B]    bit0: NaN in vel, bit1: NaN in h_final, bit2: too many atoms

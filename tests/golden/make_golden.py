@@ -317,6 +317,65 @@ def c1_chain():
          noise_checksum=np.array([float(nx.double().sum()), float(nh.double().sum())]), chain=chain)
 
 
+C2_SLICE = 16                  # molecules 0 .. 15 of the benchmark's batch
+C2_SLICE_NOISE_SEED = 5
+
+
+@torch.no_grad()
+def c2_slice_chain():
+    """The benchmarked launch itself, pinned to the reference: molecules 0..15 of
+    ``synthetic.make_batch('C2', seed=1000)`` - bench.py's batch - with bench.py's model (``torch.manual_seed(0)``, GEOM
+    hparams, 6 blocks; the weights are regenerated by the test the same way), T = 500, keep_frames = 1, sampled by the
+    UNMODIFIED ``src/edm.py::EDM.sample_chain``.  Noise: the in-kernel Philox stream restated on the CPU
+    (``oracle/philox_oracle.normal_bank``, seed 5, global molecule index = row of the batch) and fed through the patched
+    ``sample_gaussian_with_mask``.  Molecules never interact (edge_mask), so the rows a 16-molecule call produces are the rows
+    the 256-molecule launch must produce.  ~10 CPU-minutes."""
+    from oracle import philox_oracle
+    from difflinker_amd import Dynamics as OurDynamics
+    data, cfg = synthetic.make_batch('C2', seed=1000)
+    full = synthetic.sampler_inputs(data)
+    S = C2_SLICE
+    N = full['x'].shape[1]
+    inp = {k: (v.view(cfg['batch'], N * N, 1)[:S].reshape(-1, 1) if k == 'edge_mask' else v[:S]) for k, v in full.items()}
+    nf, L, T = cfg['nf'], cfg['n_layers'], cfg['T']
+    torch.manual_seed(0)                                      # bench.py: build_model
+    ours = OurDynamics(n_dims=3, in_node_nf=nf, context_node_nf=cfg['ctx'], hidden_nf=128, n_layers=L, norm_constant=1e-6,
+                       normalization='batch_norm', graph_type='FC')
+    dyn = Dynamics(n_dims=3, in_node_nf=nf, context_node_nf=cfg['ctx'], hidden_nf=128, device='cpu', n_layers=L,
+                   attention=False, tanh=False, norm_constant=1e-6, inv_sublayers=2, sin_embedding=False,
+                   normalization_factor=100, aggregation_method='sum', model='egnn_dynamics',
+                   normalization='batch_norm', centering=False, graph_type='FC')
+    dyn.load_state_dict({k: v.detach().cpu().clone() for k, v in ours.state_dict().items()}, strict=True)
+    dyn.eval()
+    rx, rh = philox_oracle.normal_bank(C2_SLICE_NOISE_SEED, S, N, nf, T + 2)
+    draws = []
+    for k in range(T + 2):
+        draws += [rx[k], rh[k]]
+    pos = [0]
+
+    def banked(size, device, node_mask):
+        d = draws[pos[0]]
+        assert tuple(d.shape) == tuple(size)
+        pos[0] += 1
+        return d * node_mask
+
+    edm = EDM(dynamics=dyn, in_node_nf=nf, n_dims=3, timesteps=500, noise_schedule='polynomial_2',
+              noise_precision=1e-5, loss_type='l2', norm_values=[1, 4, 10])
+    edm.T = T
+    orig = ref_utils.sample_gaussian_with_mask
+    ref_utils.sample_gaussian_with_mask = banked
+    try:
+        chain = edm.sample_chain(x=inp['x'], h=inp['h'], node_mask=inp['node_mask'],
+                                 fragment_mask=inp['fragment_mask'], linker_mask=inp['linker_mask'],
+                                 edge_mask=inp['edge_mask'], context=inp['context'], keep_frames=1)
+    finally:
+        ref_utils.sample_gaussian_with_mask = orig
+    assert pos[0] == 2 * (T + 2) and torch.isfinite(chain).all()
+    wsum = float(sum(v.double().abs().sum() for v in ours.state_dict().values()))
+    save('c2_slice_chain', rows=S, batch_seed=1000, noise_seed=C2_SLICE_NOISE_SEED, T=T, weight_abs_sum=np.array([wsum]),
+         sizes=inp['node_mask'].view(S, -1).sum(1).to(torch.int64), chain=chain)
+
+
 def _stub_reference_dependencies():
     """``src/lightning.py`` and ``src/datasets.py`` import RDKit, pytorch_lightning, WandB, Biopython ... at module
     top, none of which the build image has; none of them is touched by ``collate``,
@@ -452,3 +511,4 @@ if __name__ == '__main__':
     pocket_forward()
     size_gnn()
     inpainting_chain()
+    c2_slice_chain()

@@ -8,7 +8,9 @@ import torch
 from helpers import seeded_state_dict, rel_l2
 from oracle import egnn_oracle
 from oracle.egnn_oracle import EGNNConfig
-from test_gpu_parity import ragged_inputs
+from test_gpu_parity import ragged_inputs, FWD_TOLS
+
+FWD_TOL = FWD_TOLS['f16x3']          # DLConfig(..., precision = 1) below: the default arithmetic
 
 pytestmark = pytest.mark.gpu
 
@@ -44,12 +46,12 @@ def test_forward_through_raw_ctypes_matches_oracle_and_reports_errors():
         torch.cuda.synchronize()
         ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
                                            t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
-        assert rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= 2e-5 and flags.cpu().tolist() == [0, 0, 0]
-        # the velocity too: vel = x_final - x is a difference of fp32 coordinates, so both sides carry a few ulp(|x|) of
-        # absolute error in it; that floor is removed before normalising (as tests/test_gpu_parity.report does)
-        dv = float((out.cpu()[..., :3].double() - ref[..., :3].double()).norm())
-        floor = 4 * 2.0 ** -24 * float(z[..., :3].double().norm())
-        assert max(0.0, dv - floor) / float(ref[..., :3].double().norm()) <= 2e-5
+        # the suite's forward bar for the default arithmetic (tests/test_gpu_parity.FWD_TOLS['f16x3']; VERDICT round 5: 2e-5 here)
+        assert rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= FWD_TOL and flags.cpu().tolist() == [0, 0, 0]
+        # the coordinates the sampler consumes, x + vel, at the same bar; the raw velocity - a difference of fp32 coordinates,
+        # a few ulp(|x|) of absolute error on both sides - at the north-star bar (as tests/test_gpu_parity.report does)
+        assert rel_l2(z[..., :3] + out.cpu()[..., :3], z[..., :3] + ref[..., :3]) <= FWD_TOL
+        assert rel_l2(out.cpu()[..., :3], ref[..., :3]) <= 1e-4
         assert float(out.cpu()[..., :3].abs().max()) > 0
         # status codes: null pointer, negative batch, a molecule with more atoms than dl_max_atoms() (flag bit 2)
         assert lib.dl_egnn_forward_fc(model, B, N, None, p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags), p(ws), need, None) == -1
@@ -111,7 +113,7 @@ def test_team_entry_points_through_raw_ctypes():
         ref = egnn_oracle.dynamics_forward({k: v for k, v in sd.items()}, EGNNConfig(in_node_nf=nf, context_node_nf=ctx, n_layers=L),
                                            t, z, inp['node_mask'], inp['linker_mask'], inp['edge_mask'], inp['context'])
         for team in (1, 2, 4, 8):
-            assert rel_l2(outs[team][..., 3:], ref[..., 3:]) <= 2e-5
+            assert rel_l2(outs[team][..., 3:], ref[..., 3:]) <= FWD_TOL
         out = torch.empty((B, N, 3 + nf), device=d)
         flags = torch.zeros((B,), dtype=torch.int32, device=d)
         args = (model, B, N, p(xh), p(tt), 0, p(nm), p(lm), p(em), p(cx), p(out), p(flags))
@@ -124,6 +126,6 @@ def test_team_entry_points_through_raw_ctypes():
         assert lib.dl_egnn_forward_fc(*args, p(ws), need1 - 1, None) == -1
         assert lib.dl_egnn_forward_fc(*args, p(ws), need1, None) == 0                         # the callee allocates nothing
         torch.cuda.synchronize()
-        assert flags.cpu().tolist() == [0] * B and rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= 2e-5
+        assert flags.cpu().tolist() == [0] * B and rel_l2(out.cpu()[..., 3:], ref[..., 3:]) <= FWD_TOL
     finally:
         lib.dl_model_destroy(model)
