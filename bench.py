@@ -254,6 +254,7 @@ def secondary_measurements(device, a):
     (``executed_frac``: the coordinate head only for receiving atoms inside the linker mask) - VERDICT round 3."""
     from difflinker_amd import synthetic
     out = []
+    kept = {}
 
     def run(tag, config, batch, precision, note, team='auto', noise=None, sin_embedding=False, hidden_nf=128):
         data, cfg = synthetic.make_batch(config, seed=1000, batch=batch)
@@ -282,6 +283,13 @@ def secondary_measurements(device, a):
         t_k = (kms * 1e-3) if kms is not None else dt
         B = inp['x'].shape[0]
         fused = (not pockets) and kms is not None
+        if tag == 'c4_pockets' and not a.no_cpu_baseline:
+            # C4's own CPU baseline: DynamicsWithPockets.forward (src/egnn.py:471-552) of the reference
+            # where it exists, else of the port, on 8 of the 64 molecules
+            try:
+                kept['c4_cpu_baseline'] = cpu_baseline(edm, cfg, inp_cpu, 1)
+            except Exception as e:
+                kept['c4_cpu_baseline'] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
         out.append({'tag': tag, 'workload': f'{config}, batch={B}, T={cfg["T"]}, {precision}, noise={edm.noise_source}; {note}',
                     'compute_units_per_molecule': None if (pockets or not fused) else (max(2, edm.dynamics.team_for_size(B, device)) if config == 'C2L' else edm.dynamics.team_for(B)), 'molecules_per_s': B / dt, 'ms_per_chain': 1e3 * dt, 'kernel_ms': kms,
                     'roofline_frac': flops / t_k / 1e12 / peak, 'executed_frac': flops_exec / t_k / 1e12 / peak,
@@ -310,7 +318,35 @@ def secondary_measurements(device, a):
             'concurrent launch that takes the compute units the smallest molecules leave early (B = 257 was 373..389 molecules/s)')
     run('c2_hidden_64', 'C2', None, 'f16x3', "the reference's DEFAULT width hidden_nf = 64 (egnn.py:324-329; round 5: narrower networks run "
         'zero-padded on the 128-wide kernels - the same function at the 128-wide cost; fractions count the 128-wide work)', hidden_nf=64)
-    return out
+    try:
+        kept['size_gnn'] = time_size_gnn(device)
+    except Exception as e:
+        kept['size_gnn'] = {'ms_per_call': None, 'error': f'{type(e).__name__}: {e}'}
+    return out, kept
+
+
+def time_size_gnn(device, batch=64, n_calls=20):
+    """``dl_size_gnn_forward`` (csrc/size_gnn.hip: the linker-size predictor ``sample_fn`` of generate.py:110-128, SURVEY 8 row
+    f3) timed once: the reference's default sampling batch, GEOM-sized fragments, 5 layers - it runs once per batch, before
+    the chain."""
+    from difflinker_amd.datasets import collate_with_fragment_edges
+    from difflinker_amd.linker_size import SizeClassifier
+    from difflinker_amd import synthetic
+    torch.manual_seed(0)
+    clf = SizeClassifier(in_node_nf=9, hidden_nf=128, out_node_nf=20, n_layers=5, normalization='batch_norm').eval().to(device)
+    mols = synthetic.fc_molecules(batch, 50, 35, (3, 12), 9, seed=1000)
+    data = collate_with_fragment_edges(mols)
+    data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in data.items()}
+    with torch.no_grad():
+        clf.forward(data, return_loss=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_calls):
+            clf.forward(data, return_loss=False)
+        torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / n_calls
+    return {'ms_per_call': ms, 'workload': f'SizeClassifier.forward (dl_size_gnn_forward), batch {batch}, N = 50, 5 layers, hidden 128; wall time of '
+                                           f'the Python call, {n_calls} calls after 1 warm-up'}
 
 
 def eager_rocm_baseline(edm, cfg, inp_cpu, device, n_forwards=3):
@@ -499,6 +535,8 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': executed, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': executed / peak, 'traffic': traffic, 'traffic_note': traffic_note, 'peak_note': peak_note,
                          'frac_of_fp32_vector_peak': executed / FP32_MFMA_PEAK_TFLOPS,
+                         # the same executed work over the DENSE f16 MFMA peak, split terms not credited
+                         'frac_of_dense_f16_peak': executed / F16_MFMA_PEAK_TFLOPS,
                          'kernel': ('sample_chain_fc_kernel' + (' - two launches per chain (EDM.split_chain: <1,false,false> for every molecule, then '
                                                                '<1,true,false> for the big ones on teams of two; kernel_ms = both, see split_chain)'
                                                                if getattr(edm, 'split_chain', False) and split_events is not None else ''))
@@ -527,8 +565,32 @@ def main():
         if a.traffic_child:                                 # the profiled child of measure_traffic(): the launches are all it is for
             return
         # the optional companions must not cost the line: an error in one of them is recorded, not raised
+        c4_cpu = None
         if world == 1 and not a.no_secondary and a.config == 'C2' and not a.uniform_size and a.batch is None and a.T is None:
-            out['secondary'] = secondary_measurements(device, a)
+            out['secondary'], kept = secondary_measurements(device, a)
+            # the companions the driver's record must not lose (its `parsed` keeps the contract keys,
+            # `roofline` and `cpu_baseline` and drops everything else): small top-level keys AND a copy inside `roofline`
+            by_tag = {x['tag']: x for x in out['secondary']}
+            comp = {}
+            for key, tag, field in (('fp32_mode_molecules_per_s', 'c2_fp32_mode', 'molecules_per_s'),
+                                    ('fp32_mode_frac_of_fp32_mfma_peak', 'c2_fp32_mode', 'executed_frac'),
+                                    ('f16x2_molecules_per_s', 'c2_f16x2', 'molecules_per_s'),
+                                    ('c4_molecules_per_s', 'c4_pockets', 'molecules_per_s'),
+                                    ('c4_executed_frac', 'c4_pockets', 'executed_frac'),
+                                    ('c5_shard_molecules_per_s', 'c5_shard', 'molecules_per_s'),
+                                    ('c2_batch_64_molecules_per_s', 'c2_batch_64', 'molecules_per_s'),
+                                    ('c2_batch_64_executed_frac', 'c2_batch_64', 'executed_frac'),
+                                    ('c2_batch_128_molecules_per_s', 'c2_batch_128', 'molecules_per_s'),
+                                    ('c2_batch_257_molecules_per_s', 'c2_batch_257', 'molecules_per_s'),
+                                    ('c2_batch_512_molecules_per_s', 'c2_batch_512', 'molecules_per_s'),
+                                    ('c2_large_molecules_per_s', 'c2_large_molecules', 'molecules_per_s')):
+                if tag in by_tag:
+                    comp[key] = by_tag[tag][field]
+            comp['size_gnn_ms_per_call'] = kept.get('size_gnn', {}).get('ms_per_call')
+            out.update(comp)
+            out['roofline']['companions'] = comp
+            out['size_gnn'] = kept.get('size_gnn')
+            c4_cpu = kept.get('c4_cpu_baseline')
             # the library's default noise source is the reference's torch.randn call sequence (EDM.noise_source = 'torch'): its
             # figure sits at the top level beside `value`, which is measured with the in-kernel draws at every --gpus
             tn = [x for x in out['secondary'] if x['tag'] == 'c2_torch_noise']
@@ -542,6 +604,8 @@ def main():
                     out[key] = fn()
                 except Exception as e:
                     out[key] = {'value': None, 'error': f'{type(e).__name__}: {e}'}
+            if c4_cpu is not None and isinstance(out.get('cpu_baseline'), dict):
+                out['cpu_baseline']['c4_pockets'] = {k: c4_cpu.get(k) for k in ('value', 'unit', 'cores', 'kind', 'sample', 'error') if k in c4_cpu}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
