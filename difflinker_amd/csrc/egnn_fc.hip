@@ -71,6 +71,11 @@ constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
               (L_X0 % 4) == 0 && (L_Z % 4) == 0 && (L_DUMMY % 4) == 0, "16-byte alignment");
+// f16 modes (per-atom phases version 3, stream_phase): what a coordinate pass leaves in LDS for its reduction lives BEHIND the
+// weight ring (the first 64 KB from L_A, and the W2' region) - the loaders start as soon as the pair loop is over
+constexpr int L_TRIP3 = L_A + 2 * ST_CHUNK;        // slot triples [256][4]
+constexpr int L_AGGX3 = L_TRIP3 + 4 * 256;         // coordinate aggregate of the own atoms [55][4]
+static_assert(L_AGGX3 + 4 * (NMAX + 1) <= L_W && (L_TRIP3 % 4) == 0, "version-3 coordinate scratch must fit the h region");
 
 // Team kernels (several workgroups share one molecule, see team_sync): words of v.misc.  Everything a team member needs
 // is re-read from here at the point of use, so nothing of it lives in registers across the pair loops.
@@ -705,8 +710,9 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     *reinterpret_cast<float4*>(pb + 32 * mt + 8 * qq + 4 * hh) =
                         make_float4(agg[mt][4 * qq], agg[mt][4 * qq + 1], agg[mt][4 * qq + 2], agg[mt][4 * qq + 3]);
         } else if (hh == 0) {
-            // compact [slot][4] triples inside the P region: H (v.C) must survive a coordinate pass
-            *reinterpret_cast<float4*>(v.A + 4 * slot) = make_float4(ax, ay, az, 0.0f);
+            // compact [slot][4] triples inside the P region: H (v.C) must survive a coordinate pass (f16 modes, round 6:
+            // behind the weight ring of stream_phase, whose loaders start as soon as the loop is over)
+            *reinterpret_cast<float4*>(v.A + (PREC != 0 ? L_TRIP3 - L_A : 0) + 4 * slot) = make_float4(ax, ay, az, 0.0f);
         }
     }
 }
@@ -764,16 +770,19 @@ __device__ __forceinline__ float pair_reduce_gcl(const Lds& v, int nown, int nb,
 }
 // coordinate head: aggx[i][0..2] = sum of the slot triples of receiver i (thread = atom; atoms off the list keep whatever
 // aggx holds: the update skips them)
+template <bool V3>
 __device__ __forceinline__ void pair_reduce_equiv(const Lds& v, int nown, int nb, int tid, float scale) {
     const SlotPlan pl = slot_plan(v.misc[MS_NRCV], nb);
     const int k = tid < nown ? v.rpos[tid] : -1;
+    const float* trip = V3 ? v.A - L_A + L_TRIP3 : v.A;
+    float* aggx = V3 ? v.A - L_A + L_AGGX3 : v.aggx;
     if (k >= 0) {
         float sx = 0.f, sy = 0.f, sz = 0.f;
         for (int ch = 0; ch < pl.g; ++ch) {
-            const float4 p = *reinterpret_cast<const float4*>(v.A + 4 * (k * pl.g + ch));
+            const float4 p = *reinterpret_cast<const float4*>(trip + 4 * (k * pl.g + ch));
             sx += p.x; sy += p.y; sz += p.z;
         }
-        v.aggx[4 * tid + 0] = sx * scale; v.aggx[4 * tid + 1] = sy * scale; v.aggx[4 * tid + 2] = sz * scale;
+        aggx[4 * tid + 0] = sx * scale; aggx[4 * tid + 1] = sy * scale; aggx[4 * tid + 2] = sz * scale;
     }
 }
 
@@ -1414,7 +1423,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     lds_barrier();                         // partial triples complete
     // w7' carries 1/normalization_factor unless tanh or the mean need the raw head output (dl_model_create)
     const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
-    pair_reduce_equiv(v, nown, nb, tid, xscale);
+    pair_reduce_equiv<false>(v, nown, nb, tid, xscale);
     if (TEAM && tid == 0) v.fmax[FM_XOWN] = 0u;
     lds_barrier();                         // partials read: P, Q, W2' regions are free
     stage_next(v, nx, w, tid);
@@ -1448,7 +1457,449 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     open_pass<PREC, TEAM>(v, nb, nown, nx, hs, pf, pw, cx.pass + 1, cx.par);
 }
 
-template <bool TEAM>
+
+// ---------------------------------------------------------------------------------------------------
+// Per-atom phases, version 3 (round 6, f16 modes): ATOM-STATIONARY and TRANSPOSED, like the pair loop.
+//   Version 2 (above; still the exact-fp32 mode's) runs every per-atom GEMM with the atoms as MFMA rows on all eight waves: each
+//   GEMM reads the activations back from LDS fragment rows, its result goes through 32 two-byte LDS stores per lane into the
+//   next GEMM's rows, seven workgroup barriers per pass, and every wave pulls 16 KB of weight fragments per GEMM through the
+//   vector-memory path - ~830 KB per pass and compute unit at 64 B/clk, 15-20 us per GCL pass of which ~3.5 us is matrix work
+//   (profiles/r03/phase_timeline_B64_team1.log: 20 % of a forward at B = 64, 25 % at B = 256).
+//   Here a wave OWNS 16 atoms (waves 0-3: own atoms 16 w .. 16 w + 15; a 16-atom tile = the N dimension of
+//   v_mfma_f32_16x16x32_f16) and computes D = W' x X with the output FEATURES as MFMA rows: the accumulator layout - lane
+//   (atom, kg) holds features 16 ot + 4 kg + 0..3 of tile ot - IS the B-operand layout of the next GEMM once the k-slots of its
+//   weights are permuted to match (pack_layout.h: stream_kslot), so   agg -> t = SiLU(T0 + W3b' agg) -> h += W4' t + b4 ->
+//   P, Q, T0 of the next pass   is one register-to-register chain per wave: no LDS round trip, no barrier, no layout conversion
+//   between the GEMMs.  The weights - the same 64 KB for every wave - are STREAMED through LDS: waves 4-7 do nothing but issue
+//   LDS-DMA (global_load_lds_dwordx4) of 32 KB chunks into a ring of four slots (the P, Q, h and W2' regions: dead between two
+//   pair loops), two chunks ahead of the one being consumed; a chunk boundary is one workgroup barrier.  HBM scratch: the fp32
+//   node features (residual) and T0, 4 x float4 per lane and tile in accumulator order, read by the lane that wrote them.
+// ---------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ floatx4 mfma16(const uint4& a, const uint4& b, floatx4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+}
+constexpr int ST_AWAVES = 4;                       // waves 0-3: 16 atoms each; waves 4-7: the loaders
+constexpr int ST_PIECES = ST_CHUNK / 256 / 4;      // 1 KB LDS-DMA pieces per loader wave and chunk: 8
+// ring slots (floats from the LDS base): 0, 1 = the two halves of the W2' image region, 2, 3 = the first 64 KB of the P / Q / h regions
+__host__ __device__ constexpr int st_slot_off(int slot) { return slot < 2 ? L_W + slot * ST_CHUNK : L_A + (slot - 2) * ST_CHUNK; }
+static_assert(L_A + 2 * ST_CHUNK <= L_W && 2 * ST_CHUNK == UNIT, "ring slots 2, 3 must fit below the W2' region");
+// chunk c of a stream of NC chunks sits in slot (c + off) & 3 with off chosen so that the LAST two chunks use slots 2, 3: the
+// W2' image of the next pair loop (slots 0, 1) is requested two chunks before the stream ends and lands under them
+__host__ __device__ constexpr int st_slot(int c, int nc) { return (c + ((4 - nc) & 3)) & 3; }
+
+struct BOp {
+    uint4 hi[4], lo[4];                            // k-slabs 0..3 of a wave's 16 atoms: fp16 hi / lo fragments
+};
+// tile (w, ot) of the HBM scratch: [lane] float4 = features 16 ot + 4 kg + 0..3 of atom 16 w + n, lane = 16 kg + n
+__device__ __forceinline__ float4* st_tile(float* tiles, int w, int ot, int lane) {
+    return reinterpret_cast<float4*>(tiles) + (w * 8 + ot) * 64 + lane;
+}
+// fp32 rows [atom][LDH] in LDS -> the B operand of a wave's 16 atoms (rows past the last own atom: the last one's, discarded later)
+__device__ __forceinline__ void st_load_rows(BOp& b, const float* rows, int l, int kg, float s) {
+    const float* rp = rows + l * LDH + 4 * kg;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        const float4 a = *reinterpret_cast<const float4*>(rp + 32 * sl), c4 = *reinterpret_cast<const float4*>(rp + 32 * sl + 16);
+        const float u[8] = {a.x * s, a.y * s, a.z * s, a.w * s, c4.x * s, c4.y * s, c4.z * s, c4.w * s};
+        split8t(u, b.hi[sl], b.lo[sl]);
+    }
+}
+// the four output tiles of one chunk: acc[t] = W'[tile t of the chunk] x B, three split terms, smallest first
+template <int SLOT>
+__device__ __forceinline__ void st_mma_chunk(const float* lds0, const BOp& b, floatx4 (&acc)[4], int lane) {
+    const uint4* Wc = reinterpret_cast<const uint4*>(lds0 + st_slot_off(SLOT)) + lane;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+        uint4 ah[4], al[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ah[t] = Wc[((t * 4 + sl) * 2 + 0) * 64]; al[t] = Wc[((t * 4 + sl) * 2 + 1) * 64]; }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(al[t], b.hi[sl], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ah[t], b.lo[sl], acc[t]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = mfma16(ah[t], b.hi[sl], acc[t]);
+    }
+}
+// loader waves: chunk `src` (32 KB, global) -> ring slot SLOT, 8 pieces of 1 KB per wave
+template <int SLOT>
+__device__ __forceinline__ void st_issue(float* lds0, const float* __restrict__ src, int hw, int lane) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* s4 = reinterpret_cast<const float4*>(src) + lane;
+#pragma unroll
+    for (int it = 0; it < ST_PIECES; ++it) {
+        const int piece = it * 4 + hw;
+        __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(lds0 + st_slot_off(SLOT) + piece * 256), 16, 0, 0);
+    }
+}
+// loader waves: the W2' / W6' image and the four vectors of the next pair loop (stage_dma's job, on four waves)
+__device__ __forceinline__ void st_issue_image(const Lds& v, const NextPass& nx, int hw, int lane) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float* wimg = nx.base + (nx.equiv ? E_W6T : G_W2T);
+    const float* vecs = nx.base + (nx.equiv ? E_VEC : G_VEC) + HID;
+    const float* vec4 = nx.base + (nx.equiv ? E_VEC + 4 * HID : G_VEC + 6 * HID);
+    if (hw < 2) {                                  // lanes 0..95 of the pair: wr', wd', b2'|b6'; 96..127: w7' / w_att'
+        const int t2 = 64 * hw + lane;
+        const float4* src = (t2 < 96) ? reinterpret_cast<const float4*>(vecs) + t2 : reinterpret_cast<const float4*>(vec4) + (t2 - 96);
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(v.vec + 256 * hw), 16, 0, 0);
+    }
+    const float4* s4 = reinterpret_cast<const float4*>(wimg) + lane;
+#pragma unroll
+    for (int it = 0; it < UNIT / 256 / 4; ++it) {
+        const int piece = it * 4 + hw;
+        __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(v.W + piece * 256), 16, 0, 0);
+    }
+}
+constexpr int ST_IMAGE_PIECES = UNIT / 256 / 4;    // per loader wave (the vector piece of waves 4, 5 on top: waits are conservative)
+template <int N>
+__device__ __forceinline__ void st_wait_vm() {
+    if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+template <int V>
+struct IC { static constexpr int value = V; };
+
+// POST: after a GCL's pair loop (slot partials summed: `ar`, max |agg| in FM_AGG) - node MLP, then the next pass's projections;
+// !POST: the projections alone, from the node features in the HBM scratch (forward entry, after a coordinate pass).
+// NEXT_EQ: the next pass is the coordinate pass (P, Q from W5a', W5b') else a GCL (P, Q, T0 from W1a', W1b', W3a').
+// Ends like open_pass: every LDS operand of the next pair loop in place, behind a barrier.
+template <bool TEAM, bool POST, bool NEXT_EQ>
+__device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRegs* ar) {
+    constexpr int NC = (POST ? 4 : 0) + (NEXT_EQ ? 4 : 6);
+    constexpr int C_P = POST ? 4 : 0;              // first chunk of the P unit; Q follows, then T0
+    const PassCtx cx = pass_ctx(v);
+    const LaneIds q = lane_ids();
+    const int tid = q.tid, w = q.w, lane = q.lane;
+    const int nb = cx.nb;
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+    float* hs = cx.hs;
+    // the pass whose operands this phase prepares: the one after the current (forward entry: CX_PASS = -1)
+    const int pass_open = cx.pass + 1;
+    const float* wp = ctx_p<const float>(v, CX_WP);
+    const int sub = ctx_i(v, CX_SUB);
+    const float* g = POST ? cx.g : nullptr;                              // this GCL (POST)
+    const float* nxb = pass_weights(wp, pass_open, sub);                 // the pass being opened
+    const NextPass nx = {nxb, NEXT_EQ};
+    const float* sc = POST ? g + G_SCALE : nullptr;
+    const float* scn = nxb + (NEXT_EQ ? E_SCALE : G_SCALE);
+    const float* vecn = nxb + (NEXT_EQ ? E_VEC : G_VEC);
+    float* lds0 = v.A - L_A;
+    const bool loader = w >= ST_AWAVES;
+    const int hw = w - ST_AWAVES;
+    const int n = lane & 15, kg = lane >> 4;
+    const int l = 16 * w + n;                                            // own atom of this lane (atom waves)
+    const bool awave = !loader && 16 * w < nown;                         // wave-uniform
+    const bool valid = awave && l < nown;
+    const int lc = max(min(l, nown - 1), 0);
+    auto chunk_src = [&](int c) -> const float* {                        // chunk c of this phase's stream (global)
+        if (POST && c < 4) return g + G_ST_POST + c * ST_CHUNK;
+        return nxb + (NEXT_EQ ? E_ST_PRE : G_ST_PRE) + (c - C_P) * ST_CHUNK;
+    };
+    // ---- scales (a-priori bounds, exactly version 2's)
+    const int par = cx.par;
+    float hmax = 0.f, aggmax = 0.f, s_agg = 1.f, s_t = 1.f, s_hn = 1.f, inv2 = 1.f;
+    if constexpr (POST) {
+        hmax = __uint_as_float(v.fmax[FM_H0 + par]);
+        aggmax = __uint_as_float(v.fmax[FM_AGG]);
+        s_agg = scale_for(aggmax);
+        const float y3b = cload(sc, SC_L1_W3A) * hmax + cload(sc, SC_L1_W3B) * aggmax + cload(sc, SC_B3);
+        s_t = scale_for(y3b);
+        const float hnb = hmax + cload(sc, SC_L1_W4) * y3b + cload(sc, SC_B4);
+        s_hn = scale_for(hnb);
+        if (tid == 0 && (beyond_f16_range(aggmax) || beyond_f16_range(y3b) || beyond_f16_range(hnb))) atomicOr(&v.misc[1], NAN_RANGE | 3);
+        inv2 = inv_pow2(s_t * cload(sc, 4));
+    }
+    // scale of the node features as the B operand of the projections: POST - the bound of the new h; else the measured max |h|
+    const float s_hf = POST ? s_hn : scale_for(__uint_as_float(v.fmax[FM_H0 + par]));
+    // ---- the aggregate as fp32 rows (POST): into the slot the FOURTH chunk will take, free until chunk 0 has been consumed
+    constexpr int AGG_OFF = st_slot_off(st_slot(3, NC));
+    if constexpr (POST) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + THREADS * k;
+            if (e < nown * 32) *reinterpret_cast<float4*>(lds0 + AGG_OFF + (e >> 5) * LDH + 4 * (e & 31)) = ar->v[k];
+        }
+    }
+    // ---- loaders: the first three chunks
+    if (loader) {
+        st_issue<st_slot(0, NC)>(lds0, chunk_src(0), hw, lane);
+        st_issue<st_slot(1, NC)>(lds0, chunk_src(1), hw, lane);
+        st_issue<st_slot(2, NC)>(lds0, chunk_src(2), hw, lane);
+    }
+    // ---- atom waves: what the epilogues add, requested ahead (vector memory returns in order)
+    float4 t0r[8], hold[8], bb4[8];
+    if (awave) {
+        if constexpr (POST) {
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, w, ot, lane);
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) {
+                hold[ot] = *st_tile(hs + HS_HT, w, ot, lane);
+                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
+            }
+        } else {
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, w, ot, lane);
+        }
+    }
+    BOp bin, bout;                                   // the GEMM in flight reads `bin` and fills `bout`
+    floatx4 acc[4];
+    float4 Pout[8], Qout[8];
+    float hm = 0.f;
+    float S1 = 1.f;
+    if (!TEAM) {
+        const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+        S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(scn, 6)), scale_for(4.0f * x02) * scale_for(cload(scn, 7)));
+    }
+    if constexpr (!POST) {
+        // the B operand of the projections from the fp32 node features
+        if (awave) {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                const float4 a = hold[2 * sl], c4 = hold[2 * sl + 1];
+                const float u[8] = {a.x * s_hf, a.y * s_hf, a.z * s_hf, a.w * s_hf, c4.x * s_hf, c4.y * s_hf, c4.z * s_hf, c4.w * s_hf};
+                split8t(u, bin.hi[sl], bin.lo[sl]);
+            }
+        }
+    }
+    // ---- the stream: one step per chunk.  Loaders: chunk C has landed -> barrier -> request chunk C + 2 (the slot of chunk
+    // C - 2 is free: every atom wave is past it) and, two chunks before the end, the next pair loop's image.
+    // Atom waves: barrier -> the four output tiles of chunk C -> their epilogue.
+    auto step = [&](auto C_) {
+        constexpr int C = decltype(C_)::value;
+        if (loader) {
+            // outstanding behind chunk C at this point: chunk C + 1 (and C + 2 while C == 0), the image once requested
+            constexpr int behind = (C + 1 < NC ? ST_PIECES : 0) + (C == 0 && C + 2 < NC ? ST_PIECES : 0) + (C == NC - 1 ? ST_IMAGE_PIECES : 0);
+            st_wait_vm<behind>();
+        }
+        lds_barrier();
+        if (loader) {
+            if constexpr (C >= 1 && C + 2 < NC) st_issue<st_slot(C + 2, NC)>(lds0, chunk_src(C + 2), hw, lane);
+            if constexpr (C == NC - 2) st_issue_image(v, nx, hw, lane);
+            return;
+        }
+        if (!awave) return;
+        if constexpr (POST && C == 0) st_load_rows(bin, lds0 + AGG_OFF, lc, kg, s_agg);
+        st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
+        constexpr int half = C & 1;                  // tiles 4 half .. 4 half + 3 of the unit = k-slabs 2 half, 2 half + 1 of its result
+        if constexpr (POST && C < 2) {
+            // node MLP layer 1: t = SiLU(T0 + W3b' agg), times s_t 2^n_tile
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float u[8];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int ot = 4 * half + 2 * sp + tt, nt = ot >> 1;
+                    const float inv = inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)), stn = s_t * cload(sc, GS_NT + nt);
+                    const float4 t0 = t0r[ot];
+                    const float t0v[4] = {t0.x, t0.y, t0.z, t0.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[4 * tt + i] = silu_u(fmaf(acc[2 * sp + tt][i], inv, t0v[i])) * stn;
+                }
+                split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
+            }
+            if constexpr (C == 1) bin = bout;
+        } else if constexpr (POST && C < 4) {
+            // node MLP layer 2 + residual: the new h -> HBM scratch (fp32), max |h|, B operand of the projections
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float u[8];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int ot = 4 * half + 2 * sp + tt;
+                    const float4 hd = hold[ot], b4 = bb4[ot];
+                    const float hv[4] = {fmaf(acc[2 * sp + tt][0], inv2, hd.x + b4.x), fmaf(acc[2 * sp + tt][1], inv2, hd.y + b4.y),
+                                         fmaf(acc[2 * sp + tt][2], inv2, hd.z + b4.z), fmaf(acc[2 * sp + tt][3], inv2, hd.w + b4.w)};
+                    *st_tile(hs + HS_HT, w, ot, lane) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        u[4 * tt + i] = hv[i] * s_hn;
+                        hm = fmaxf(hm, valid ? fabsf(hv[i]) : 0.0f);
+                    }
+                }
+                split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
+            }
+            if constexpr (C == 3) {
+                bin = bout;
+                block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
+            }
+        } else if constexpr (C < C_P + 2) {
+            // P = W1a' h + b1 (W5a' h + b5): kept in registers until the ring has let go of the P region
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ot = 4 * half + t, nt = ot >> 1;
+                const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + nt));
+                const float4 b1 = *reinterpret_cast<const float4*>(vecn + 16 * ot + 4 * kg);
+                Pout[ot] = make_float4(fmaf(acc[t][0], inv, b1.x), fmaf(acc[t][1], inv, b1.y), fmaf(acc[t][2], inv, b1.z), fmaf(acc[t][3], inv, b1.w));
+            }
+        } else if constexpr (C < C_P + 4) {
+            // Q = W1b' h (W5b' h), times the geometric scale S1 (a team applies its own after the exchange)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ot = 4 * half + t, nt = ot >> 1;
+                const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + 4 + nt)) * S1;
+                Qout[ot] = make_float4(acc[t][0] * inv, acc[t][1] * inv, acc[t][2] * inv, acc[t][3] * inv);
+            }
+        } else {
+            // T0 = W3a' h + b3 of the GCL being opened -> HBM scratch
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ot = 4 * half + t, nt = ot >> 1;
+                const float inv = inv_pow2(s_hf * cload(scn, GS_SW_W3A + nt));
+                const float4 b3 = *reinterpret_cast<const float4*>(vecn + 4 * HID + 16 * ot + 4 * kg);
+                *st_tile(hs + HS_T0, w, ot, lane) = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y),
+                                                                fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
+            }
+        }
+    };
+    step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
+    if constexpr (NC > 4) { step(IC<4>{}); step(IC<5>{}); }
+    if constexpr (NC > 6) { step(IC<6>{}); step(IC<7>{}); }
+    if constexpr (NC > 8) { step(IC<8>{}); step(IC<9>{}); }
+    lds_barrier();                                   // the ring is done: the P and Q regions are free
+    if (valid) {
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) {
+            *reinterpret_cast<float4*>(v.A + l * LDH + 16 * ot + 4 * kg) = Pout[ot];
+            *reinterpret_cast<float4*>(v.B + l * LDH + 16 * ot + 4 * kg) = Qout[ot];
+        }
+    }
+    if (tid == 0) {
+        if constexpr (POST) { v.fmax[FS_HS] = __float_as_uint(s_hn); v.misc[CX_PAR] = par ^ 1; }
+        v.misc[CX_PASS] = pass_open;
+    }
+    if constexpr (TEAM) {
+        prof_event(pf, w, lane, 110);
+        lds_barrier();                               // own Q rows complete
+        team_exchange_q<1>(v, nb, tid, scn, pass_open == 0, POST ? (par ^ 1) : par, pf);
+    }
+    prof_event(pf, w, lane, 11);
+    dma_wait();                                      // (loaders: the image; atom waves: their scratch stores are not waited for by anybody else)
+    lds_barrier();
+}
+
+
+// GCL (egnn.py:45-80), per-atom phases version 3 (f16 modes): the pair loop as before, then stream_phase
+template <int PREC, bool TEAM, bool ATT>
+__device__ __forceinline__ void gcl_pass3(const Lds& v, Prof& pf) {
+    {   // ---- pair loop (version 2's, unchanged)
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N, par = cx.par;
+    const int8_t* emask = cx.em;
+    const float* sc = cx.g + G_SCALE;
+    const LaneIds q = lane_ids();
+    const int tid = q.tid, w = q.w, lane = q.lane;
+    prof_event(pf, w, lane, 12);
+    if (tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
+    const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
+    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+    const float pqb = (cload(sc, SC_L1_W1A) + cload(sc, SC_L1_W1B)) * hmax + cload(sc, SC_B1);
+    const float u1b = pqb + 4.0f * (x2 * cload(sc, GS_WRW) + x02 * cload(sc, GS_WDW));
+    const float sa = scale_for(u1b);
+    const float accs = sa * cload(sc, 5);
+    if (tid == 0 && (beyond_f16_range(u1b) || beyond_f16_range(hmax) || beyond_f16_range(4.0f * x2) || beyond_f16_range(4.0f * x02)))
+        atomicOr(&v.misc[1], NAN_RANGE | 3);
+    if constexpr (ATT) pair_phase<false, PREC, true, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, cload(sc, 8), pf);
+    else pair_phase<false, PREC, false, TEAM>(v, nb, w, lane, emask, N, 0.0f, sa, inv_pow2(accs), sc, 0.0f, pf);
+    prof_event(pf, w, lane, 13);
+    }
+    AggRegs ar;
+    bool next_eq;
+    {
+        const PassCtx cx = pass_ctx(v);
+        const int nown = TEAM ? ctx_i(v, TM_NOWN) : cx.nb;
+        const LaneIds q = lane_ids();
+        next_eq = cx.nx.equiv;
+        lds_barrier();                         // partial rows complete
+        prof_event(pf, q.w, q.lane, 20);
+        const float am = pair_reduce_gcl(v, nown, cx.nb, q.tid, ar, (cx.flags & 4) ? 1.0f / float(cx.N) : 1.0f);
+        block_max(&v.fmax[FM_AGG], am, q.lane);
+        prof_event(pf, q.w, q.lane, 21);
+        lds_barrier();                         // every partial read: the P, Q, h, W2' regions are free; max |agg| known
+        prof_event(pf, q.w, q.lane, 22);
+    }
+    if (next_eq) stream_phase<TEAM, true, true>(v, pf, &ar);
+    else stream_phase<TEAM, true, false>(v, pf, &ar);
+}
+
+// EquivariantUpdate (egnn.py:101-125), per-atom phases version 3 (f16 modes)
+template <int PREC, bool TEAM>
+__device__ __forceinline__ void equiv_pass3(const Lds& v, Prof& pf) {
+    {   // ---- pair loop (version 2's)
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N, par = cx.par;
+    const int8_t* emask = cx.em;
+    const float* sc = cx.g + E_SCALE;
+    const float norm_constant = ctx_f(v, CX_NORMC);
+    const LaneIds q = lane_ids();
+    const int w = q.w, lane = q.lane;
+    prof_event(pf, w, lane, 32);
+    const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
+    const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
+    const float pqb = (cload(sc, SCE_L1_W5A) + cload(sc, SCE_L1_W5B)) * hmax + cload(sc, SCE_B5);
+    const float u1b = pqb + 4.0f * (x2 * cload(sc, ES_WRW) + x02 * cload(sc, ES_WDW));
+    const float sa = scale_for(u1b);
+    const float accs = sa * cload(sc, 2);
+    if (q.tid == 0 && (beyond_f16_range(u1b) || beyond_f16_range(hmax) || beyond_f16_range(4.0f * x2) || beyond_f16_range(4.0f * x02)))
+        atomicOr(&v.misc[1], NAN_RANGE | 3);
+    // (the finiteness proof of the skipped sums: see equiv_pass2)
+    const float phi = cload(sc, ES_W7L1) * fmaf(cload(sc, ES_L1_W6), u1b, cload(sc, ES_B6));
+    const bool proven = 2.0f * float(nb) * phi < 1e37f;
+    if (!proven) {
+        const bool widen = ctx_i(v, MS_FULL) == 0;
+        __syncthreads();
+        if (widen) {
+            const int tid_ = q.tid;
+            receivers_all(v, TEAM ? ctx_i(v, TM_NOWN) : nb, tid_);
+            __syncthreads();
+        }
+    }
+    pair_phase<true, PREC, false, TEAM>(v, nb, w, lane, emask, N, norm_constant, sa, inv_pow2(accs), sc,
+                                        (cx.flags & 2) ? ctx_f(v, CX_CRANGE) : 0.0f, pf);
+    prof_event(pf, w, lane, 33);
+    }
+    // ---- coordinate update of the own atoms
+    const PassCtx cx = pass_ctx(v);
+    const int nb = cx.nb, N = cx.N;
+    const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
+    const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
+    const bool more = cx.nx.base != nullptr;
+    const LaneIds q = lane_ids();
+    const int tid = q.tid, lane = q.lane;
+    lds_barrier();                         // partial triples complete
+    const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
+    pair_reduce_equiv<true>(v, nown, nb, tid, xscale);
+    if (tid == 0) v.fmax[TEAM ? FM_XOWN : FM_X2] = 0u;
+    lds_barrier();
+    const float* aggx = v.A - L_A + L_AGGX3;
+    float n2 = 0.0f;
+    if (tid < nown) {
+        const float lm = v.lm[tid];
+        const int a = rank + tid * S;
+        const bool moves = v.rpos[tid] >= 0;                     // off the receiver list: linker mask 0, nothing was summed
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float xn = v.xs[4 * a + k];
+            if (moves) {
+                xn += aggx[4 * tid + k] * lm;
+                v.xs[4 * a + k] = xn;
+            }
+            n2 = fmaf(xn, xn, n2);
+        }
+    }
+    block_max(&v.fmax[TEAM ? FM_XOWN : FM_X2], n2, lane);       // (a team: the own atoms; the exchange headers carry it)
+    prof_event(pf, q.w, lane, 34);
+    lds_barrier();
+    prof_event(pf, q.w, lane, 10);
+    if (more) stream_phase<TEAM, false, false>(v, pf, nullptr);
+}
+
+template <bool TEAM, bool V3>
 __device__ __forceinline__ void head_phase(const Lds& v);
 
 // Dynamics.forward for the own atoms of the molecule resident in LDS: reads v.z (state), the linker mask v.lm, the context
@@ -1467,7 +1918,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int npass = ctx_i(v, CX_NPASS);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    if (tid == 0) { v.misc[CX_PASS] = 0; v.misc[CX_PAR] = 0; }
+    if (tid == 0) { v.misc[CX_PASS] = (PREC != 0) ? -1 : 0; v.misc[CX_PAR] = 0; }     // (version 3 opens pass CX_PASS + 1: stream_phase)
     if (tid < 8) reinterpret_cast<int*>(v.A - L_A + L_PROG)[tid] = 0;      // pair-loop progress slots (pair_phase); barriers follow
     prof_event(pf, w, lane, 1);
     {
@@ -1475,7 +1926,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         __syncthreads();
     }
     const NextPass first = {wp + OFF_BLOCKS, false};
-    stage_next(v, first, w, tid);                                   // first pass's W2' image (v.W, v.vec are free here)
+    if constexpr (PREC == 0) stage_next(v, first, w, tid);          // first pass's W2' image (v.W, v.vec are free here); version 3: its loaders'
     // coordinates at entry of the own atoms (x, and x0 for the d0 edge attribute and the velocity); a team gets everybody's
     // from its first exchange
     if (tid < 4 * nown) {
@@ -1522,24 +1973,41 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
                 else if (k < fin) hin = ctxp[pos * nctx + (k - nf - ct)];
                 acc = fmaf(wrow[k], hin, acc);
             }
+            if constexpr (PREC != 0) {
+                // version 3: st_tile's layout - tile (l / 16, f / 16), lane 16 ((f / 4) & 3) + l % 16, component f & 3
+                hs[HS_HT + ((((l >> 4) * 8 + (f >> 4)) * 64 + 16 * ((f >> 2) & 3) + (l & 15)) * 4) + (f & 3)] = acc;
+            } else {
             v.B[l * LDH + f] = acc;
             {   // accumulator-tile copy (tile_store16's layout): row l of tile (l / 32, f / 32) sits in register (r & 3) + 4 (r >> 3) of lane half (r >> 2) & 1
                 const int r = l & 31;
                 hs[HS_HT + ((((l >> 5) * 4 + (f >> 5)) * 4 + (r >> 3)) * 64 + (f & 31) + 32 * ((r >> 2) & 1)) * 4 + (r & 3)] = acc;
+            }
             }
             hmax = fmaxf(hmax, fabsf(acc));
         }
         block_max(&v.fmax[FM_H0], hmax, lane);
     }
     __syncthreads();
+    if constexpr (PREC != 0) {
+        // version 3: the node features live in the HBM scratch (fp32, written above); the projections of the first pass
+        if (tid == 0 && beyond_f16_range(__uint_as_float(v.fmax[FM_H0]))) atomicOr(&v.misc[1], NAN_RANGE | 3);
+        prof_event(pf, w, lane, 2);
+        stream_phase<TEAM, false, false>(v, pf, nullptr);
+        const int sub = ctx_i(v, CX_SUB);
+#pragma nounroll
+        for (int p = 0; p < npass; p += sub + 1) {
+#pragma nounroll
+            for (int gi = 0; gi < sub; ++gi) gcl_pass3<PREC, TEAM, ATT>(v, pf);
+            equiv_pass3<PREC, TEAM>(v, pf);
+        }
+        prof_event(pf, w, lane, 3);
+        __syncthreads();                                           // the h tiles in the HBM scratch: written by other lanes
+        head_phase<TEAM, true>(v);
+    } else {
     {   // fragment rows of the embedded h -> v.C
-        const float s0 = (PREC != 0) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
+        const float s0 = 1.0f;
         for (int e = tid; e < nown * 32; e += THREADS)
             put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), *reinterpret_cast<const float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)), s0);
-        if (PREC != 0 && tid == 0) {
-            v.fmax[FS_HS] = __float_as_uint(s0);
-            if (beyond_f16_range(__uint_as_float(v.fmax[FM_H0]))) atomicOr(&v.misc[1], NAN_RANGE | 3);
-        }
     }
     __syncthreads();
     prof_event(pf, w, lane, 2);
@@ -1558,12 +2026,13 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     prof_event(pf, w, lane, 3);
     __syncthreads();                                               // the h tiles in the HBM scratch: written by other lanes
     // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
-    head_phase<TEAM>(v);
+    head_phase<TEAM, false>(v);
+    }
     prof_event(pf, w, lane, 4);
 }
 
 // (its own context reads: the pass loop above must not keep these alive)
-template <bool TEAM>
+template <bool TEAM, bool V3>
 __device__ __forceinline__ void head_phase(const Lds& v) {
     const int tid = lane_ids().tid;
     const int nb = ctx_i(v, 0), nf = ctx_i(v, CX_NF);
@@ -1577,9 +2046,22 @@ __device__ __forceinline__ void head_phase(const Lds& v) {
         const int a = e / nf, o = e - a * nf;
         // row a of the accumulator-order tiles: 32 consecutive floats per feature tile (k ascending: the reference's order)
         const int r = a & 31;
-        const float* hp = hs + HS_HO + ((a >> 5) * 4 * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1);
         const float* wo = wp + OFF_OUT_W + o * HID;
         float acc = wp[OFF_OUT_B + o];
+        if constexpr (V3) {
+            // per-atom phases version 3: the node features of atom a in the tiles of wave a / 16 (st_tile), k ascending as well
+            const float* hp = hs + HS_HT + ((a >> 4) * 8 * 64 + (a & 15)) * 4;
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot)
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+                    const float4 hv = *reinterpret_cast<const float4*>(hp + (ot * 64 + 16 * kg) * 4);
+                    const float4 wv = *reinterpret_cast<const float4*>(wo + 16 * ot + 4 * kg);
+                    acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc);
+                    acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
+                }
+        } else {
+        const float* hp = hs + HS_HO + ((a >> 5) * 4 * 16 + (r & 3) + 4 * (r >> 3)) * 64 + 32 * ((r >> 2) & 1);
 #pragma unroll
         for (int nt4 = 0; nt4 < 4; ++nt4)
 #pragma unroll 8
@@ -1589,6 +2071,8 @@ __device__ __forceinline__ void head_phase(const Lds& v) {
                 acc = fmaf(hv.x, wv.x, acc); acc = fmaf(hv.y, wv.y, acc);
                 acc = fmaf(hv.z, wv.z, acc); acc = fmaf(hv.w, wv.w, acc);
             }
+        }
+        (void)r;
         eps[a * DMAX + 3 + o] = acc;
         if (acc != acc) nanbits |= 2;
     }
@@ -2105,6 +2589,28 @@ void pack_unit_f16(float* dstf, const float* w, int ld, int col0, double scale, 
     }
 }
 
+// f16x3 A-operand stream unit (pack_layout.h: G_ST_*): unit[chunk][ot & 3][slab][part][lane][e], ot = 4 chunk + (ot & 3),
+// value = part(sw * W'[f = 16 ot + (lane & 15)][col0 + stream_kslot(slab, lane >> 4, e)]); sw: one power of two per 32 output
+// rows (`tile` = true: the first-layer matrices, as pack_unit_f16) or per matrix (W4', as pack_unit_f16_uniform)
+void pack_stream_f16(float* dstf, const float* w, int ld, int col0, double scale, bool tile) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dstf);
+    const double sw_all = tile ? 1.0 : f16_weight_scale(w, ld, col0, HID, scale);
+    for (int ot = 0; ot < 8; ++ot) {
+        const double sw = tile ? f16_tile_scale(w, ld, col0, 32 * (ot >> 1), scale) : sw_all;
+        for (int slab = 0; slab < 4; ++slab)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int e = 0; e < 8; ++e) {
+                    const int f = 16 * ot + (lane & 15);
+                    const int k = stream_kslot(slab, lane >> 4, e);
+                    uint16_t hi, lo;
+                    split_f16(double(w[size_t(f) * ld + col0 + k]) * scale * sw, hi, lo);
+                    const size_t base = (size_t((ot >> 2) * 4 + (ot & 3)) * 4 + slab) * 2;
+                    dst[((base + 0) * 64 + lane) * 8 + e] = hi;
+                    dst[((base + 1) * 64 + lane) * 8 + e] = lo;
+                }
+    }
+}
+
 // f16x3 LDS image: img[part*8 + slab][nt][lane][e]
 double pack_lds_image_f16(float* dstf, const float* w, int ld, double scale) {
     const double sw = f16_weight_scale(w, ld, 0, HID, scale);
@@ -2400,6 +2906,12 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
                 pack_unit_f16(g + G_W3B, w3p.data(), 2 * HID, HID, s3b, sc + GS_SW_W3B);
                 // W4': its rows are the node features themselves (no renumbering there): one scale for the matrix
                 sc[4] = float(pack_unit_f16_uniform(g + G_W4, w4p.data(), HID, 0, 1.0 / c));
+                // the same matrices as the A-operand stream of the atom-stationary per-atom phases (round 6)
+                pack_stream_f16(g + G_ST_POST, w3p.data(), 2 * HID, HID, s3b, true);
+                pack_stream_f16(g + G_ST_POST + UNIT, w4p.data(), HID, 0, 1.0 / c, false);
+                pack_stream_f16(g + G_ST_PRE, w1p.data(), ld1, 0, c, true);
+                pack_stream_f16(g + G_ST_PRE + UNIT, w1p.data(), ld1, HID, c, true);
+                pack_stream_f16(g + G_ST_PRE + 2 * UNIT, w3p.data(), 2 * HID, 0, c, true);
             } else {
                 pack_unit(g + G_W1A, w1p.data(), ld1, 0, c); pack_unit(g + G_W1B, w1p.data(), ld1, HID, c);
                 pack_unit(g + G_W3A, w3p.data(), 2 * HID, 0, c); pack_unit(g + G_W3B, w3p.data(), 2 * HID, HID, s3b);
@@ -2455,6 +2967,8 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
         if (f16) {
             pack_unit_f16(e + E_W5A, w1p.data(), ld5, 0, c, sc + ES_SW_W5A);
             pack_unit_f16(e + E_W5B, w1p.data(), ld5, HID, c, sc + ES_SW_W5B);
+            pack_stream_f16(e + E_ST_PRE, w1p.data(), ld5, 0, c, true);
+            pack_stream_f16(e + E_ST_PRE + UNIT, w1p.data(), ld5, HID, c, true);
         } else {
             pack_unit(e + E_W5A, w1p.data(), ld5, 0, c); pack_unit(e + E_W5B, w1p.data(), ld5, HID, c);
             for (int k = 0; k < 8; ++k) sc[ES_SW_W5A + k] = 1.0f;

@@ -51,7 +51,15 @@ constexpr int GS_WRW = 52, GS_WDW = 53;              // max over features of 2^n
 constexpr int G_SCALE_SIZE = 64;
 constexpr int G_WG = G_SCALE + G_SCALE_SIZE;         // sin_embedding: the 24 embedded-distance columns of edge_mlp.0, [k][128], times c
 constexpr int SIN_K = 24;                            // 6 frequencies x (sin, cos) x (radial, d0)   (egnn.py:281-292, :159-161, :221-222)
-constexpr int GCL_SIZE = 7 * UNIT + 7 * HID + G_SCALE_SIZE + SIN_K * HID;
+// ---- round 6, f16 modes: the same five per-atom matrices once more, as the A-OPERAND STREAM of the atom-stationary per-atom
+// phases of egnn_fc.hip (stream_phase): 16-feature output tiles x 32-wide k-slabs of v_mfma_f32_16x16x32_f16, in the order they
+// are consumed - a unit = two 32 KB chunks of four output tiles, chunk[ot][slab][hi | lo][lane][8 fp16], lane (r, kg) holding
+// part(sw * W'[16 ot + r][kslot(slab, kg, e)]) with the k-slots in the order the previous GEMM's accumulators leave them
+// (stream_kslot).  G_ST_POST: W3b', W4' (after this GCL's pair loop); G_ST_PRE: W1a', W1b', W3a' (what opens this GCL).
+// Same weights, scales and renumbering as the units above (one sc[] block serves both); the exact-fp32 mode leaves them zero.
+constexpr int G_ST_POST = 7 * UNIT + 7 * HID + G_SCALE_SIZE + SIN_K * HID;
+constexpr int G_ST_PRE = G_ST_POST + 2 * UNIT;
+constexpr int GCL_SIZE = G_ST_PRE + 3 * UNIT;
 // equivariant update: units W5a', W5b', W6' (both LDS images), vectors
 constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT, E_W6T = 3 * UNIT;
 constexpr int E_VEC = 4 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
@@ -64,7 +72,12 @@ constexpr int ES_WRW = 32, ES_WDW = 33;
 constexpr int ES_L1_W6 = 34, ES_B6 = 35, ES_W7L1 = 36;
 constexpr int E_SCALE_SIZE = 48;
 constexpr int E_WG = E_SCALE + E_SCALE_SIZE;         // sin_embedding: the same for coord_mlp.0
-constexpr int EQ_SIZE = 4 * UNIT + 5 * HID + E_SCALE_SIZE + SIN_K * HID;
+constexpr int E_ST_PRE = 4 * UNIT + 5 * HID + E_SCALE_SIZE + SIN_K * HID;      // stream units W5a', W5b' (see G_ST_*)
+constexpr int EQ_SIZE = E_ST_PRE + 2 * UNIT;
+// k-slot (slab, kg, e) of the stream's B operand = feature 32 slab + 4 kg + (e & 3) + 16 (e >> 2): lane (atom, kg) of a 16x16
+// accumulator tile ot holds features 16 ot + 4 kg + 0..3, so the tiles 2 slab and 2 slab + 1 ARE k-slab `slab` of the next GEMM
+__host__ __device__ inline int stream_kslot(int slab, int kg, int e) { return 32 * slab + 4 * kg + (e & 3) + 16 * (e >> 2); }
+constexpr int ST_CHUNK = UNIT / 2;                    // floats of one 32 KB chunk
 constexpr int MAX_SUBLAYERS = 4;                     // inv_sublayers: GCLs per block (reference default and every released config: 2)
 __host__ __device__ inline size_t block_size(int sublayers) { return size_t(sublayers) * GCL_SIZE + EQ_SIZE; }
 
