@@ -131,6 +131,16 @@ __device__ __forceinline__ void prof_event(Prof& pf, int w, int lane, int tag) {
 #endif
 }
 
+// the chunk-level events of stream_phase (an event costs a few hundred cycles - s_memtime, two stores - and ~20 of them sit in a
+// phase of ~20 K cycles): -DDL_PROFILE_FINE builds only
+__device__ __forceinline__ void fine_event(Prof& pf, int w, int lane, int tag) {
+#ifdef DL_PROFILE_FINE
+    prof_event(pf, w, lane, tag);
+#else
+    (void)pf; (void)w; (void)lane; (void)tag;
+#endif
+}
+
 // events INSIDE the pair loop perturb it (the profile state lives across the loop): -DDL_PROFILE_LOOP builds only
 __device__ __forceinline__ void loop_event(Prof& pf, int w, int lane, int tag) {
 #ifdef DL_PROFILE_LOOP
@@ -1505,7 +1515,11 @@ __device__ __forceinline__ void st_load_rows(BOp& b, const float* rows, int l, i
         split8t(u, b.hi[sl], b.lo[sl]);
     }
 }
-// the four output tiles of one chunk: acc[t] = W'[tile t of the chunk] x B, three split terms, smallest first
+// the four output tiles of one chunk: acc[t] = W'[tile t of the chunk] x B, three split terms, smallest first; tile 0, 1, 2, 3 for
+// each term: an accumulator is touched every fourth matrix instruction.
+// (ordered by the compiler: a hand-pipelined variant - fragments of k-slab s + 1 requested before the MFMAs of slab s,
+// sched_barrier after every MFMA - keeps a clean 0 1 2 3 round robin where the scheduler walks the tiles back and forth, but its
+// 64 fragment registers push ~50 others of the kernel into scratch and measured 1 % WORSE, round 6)
 template <int SLOT>
 __device__ __forceinline__ void st_mma_chunk(const float* lds0, const BOp& b, floatx4 (&acc)[4], int lane) {
     const uint4* Wc = reinterpret_cast<const uint4*>(lds0 + st_slot_off(SLOT)) + lane;
@@ -1514,14 +1528,24 @@ __device__ __forceinline__ void st_mma_chunk(const float* lds0, const BOp& b, fl
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) {
         uint4 ah[4], al[4];
+#ifdef DL_KO_DSR
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { ah[t] = b.hi[(sl + t) & 3]; al[t] = b.lo[(sl + t) & 3]; }
+#else
 #pragma unroll
         for (int t = 0; t < 4; ++t) { ah[t] = Wc[((t * 4 + sl) * 2 + 0) * 64]; al[t] = Wc[((t * 4 + sl) * 2 + 1) * 64]; }
+#endif
+#ifdef DL_KO_MFMA
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { acc[t][0] += __uint_as_float(al[t].x ^ ah[t].y); acc[t][1] += __uint_as_float(al[t].z ^ ah[t].w); }
+#else
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(al[t], b.hi[sl], acc[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(ah[t], b.lo[sl], acc[t]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] = mfma16(ah[t], b.hi[sl], acc[t]);
+#endif
     }
 }
 // loader waves: chunk `src` (32 KB, global) -> ring slot SLOT, 8 pieces of 1 KB per wave
@@ -1530,32 +1554,50 @@ __device__ __forceinline__ void st_issue(float* lds0, const float* __restrict__ 
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const float4* s4 = reinterpret_cast<const float4*>(src) + lane;
+#ifdef DL_KO_DMA
+    (void)s4; (void)lds0; (void)hw;
+#else
 #pragma unroll
     for (int it = 0; it < ST_PIECES; ++it) {
         const int piece = it * 4 + hw;
         __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(lds0 + st_slot_off(SLOT) + piece * 256), 16, 0, 0);
     }
+#endif
+}
+// every wave: its eighth of a chunk (the first chunk of a stream)
+template <int SLOT>
+__device__ __forceinline__ void st_issue8(float* lds0, const float* __restrict__ src, int w, int lane) {
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    const float4* s4 = reinterpret_cast<const float4*>(src) + lane;
+#ifndef DL_KO_DMA
+#pragma unroll
+    for (int it = 0; it < ST_PIECES / 2; ++it) {
+        const int piece = it * 8 + w;
+        __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(lds0 + st_slot_off(SLOT) + piece * 256), 16, 0, 0);
+    }
+#endif
 }
 // loader waves: the W2' / W6' image and the four vectors of the next pair loop (stage_dma's job, on four waves)
+template <int HALF>
 __device__ __forceinline__ void st_issue_image(const Lds& v, const NextPass& nx, int hw, int lane) {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
     const float* wimg = nx.base + (nx.equiv ? E_W6T : G_W2T);
     const float* vecs = nx.base + (nx.equiv ? E_VEC : G_VEC) + HID;
     const float* vec4 = nx.base + (nx.equiv ? E_VEC + 4 * HID : G_VEC + 6 * HID);
-    if (hw < 2) {                                  // lanes 0..95 of the pair: wr', wd', b2'|b6'; 96..127: w7' / w_att'
+    if (HALF == 1 && hw < 2) {                     // lanes 0..95 of the pair: wr', wd', b2'|b6'; 96..127: w7' / w_att'
         const int t2 = 64 * hw + lane;
         const float4* src = (t2 < 96) ? reinterpret_cast<const float4*>(vecs) + t2 : reinterpret_cast<const float4*>(vec4) + (t2 - 96);
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(v.vec + 256 * hw), 16, 0, 0);
     }
     const float4* s4 = reinterpret_cast<const float4*>(wimg) + lane;
 #pragma unroll
-    for (int it = 0; it < UNIT / 256 / 4; ++it) {
-        const int piece = it * 4 + hw;
+    for (int it = 0; it < ST_PIECES; ++it) {       // 32 KB = the ring slot this half of the image region was
+        const int piece = HALF * 32 + it * 4 + hw;
         __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(v.W + piece * 256), 16, 0, 0);
     }
 }
-constexpr int ST_IMAGE_PIECES = UNIT / 256 / 4;    // per loader wave (the vector piece of waves 4, 5 on top: waits are conservative)
 template <int N>
 __device__ __forceinline__ void st_wait_vm() {
     if constexpr (N <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1589,11 +1631,16 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     const float* scn = nxb + (NEXT_EQ ? E_SCALE : G_SCALE);
     const float* vecn = nxb + (NEXT_EQ ? E_VEC : G_VEC);
     float* lds0 = v.A - L_A;
+#ifdef DL_ST_EVEN
+    const bool loader = (w & 1) != 0;                                    // (experiment: atom waves 0, 2, 4, 6)
+    const int hw = w >> 1, wa = w >> 1;
+#else
     const bool loader = w >= ST_AWAVES;
-    const int hw = w - ST_AWAVES;
+    const int hw = w - ST_AWAVES, wa = w;
+#endif
     const int n = lane & 15, kg = lane >> 4;
-    const int l = 16 * w + n;                                            // own atom of this lane (atom waves)
-    const bool awave = !loader && 16 * w < nown;                         // wave-uniform
+    const int l = 16 * wa + n;                                           // own atom of this lane (atom waves)
+    const bool awave = !loader && 16 * wa < nown;                        // wave-uniform
     const bool valid = awave && l < nown;
     const int lc = max(min(l, nown - 1), 0);
     auto chunk_src = [&](int c) -> const float* {                        // chunk c of this phase's stream (global)
@@ -1625,26 +1672,61 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
             if (e < nown * 32) *reinterpret_cast<float4*>(lds0 + AGG_OFF + (e >> 5) * LDH + 4 * (e & 31)) = ar->v[k];
         }
     }
-    // ---- loaders: the first three chunks
+    // ---- TWO PROGRAMS from here to the end of the ring, one per wave kind, with the same number of workgroup barriers and no
+    // control-flow merge in between: the compiler's wait-count pass treats an LDS-DMA in flight on ANY path into a block as
+    // a reason to drain the vector-memory counter before the block's first LDS read - with the loaders' requests and the atom
+    // waves' LDS reads in one flow, every chunk of an atom wave began with s_waitcnt vmcnt(0), i.e. with a wait for its own
+    // scratch stores and bias loads (measured round 6: 2.4 K cycles per chunk instead of 0.9 K)
     if (loader) {
+        // chunk C has landed -> barrier -> request chunk C + 2 (the slot of chunk C - 2 is free: every atom wave is past
+        // it) and, two chunks before the end, the next pair loop's image
+        // (chunk 0 ALONE first: issuing a 1 KB piece costs a wave ~90 cycles, and nothing can start before this chunk has
+        // landed - chunks 1 and 2 follow behind the first barrier, under the atom waves' work on chunk 0)
         st_issue<st_slot(0, NC)>(lds0, chunk_src(0), hw, lane);
-        st_issue<st_slot(1, NC)>(lds0, chunk_src(1), hw, lane);
-        st_issue<st_slot(2, NC)>(lds0, chunk_src(2), hw, lane);
-    }
+        prof_event(pf, w, lane, 200);
+        auto lstep = [&](auto C_) {
+            constexpr int C = decltype(C_)::value;
+            // outstanding behind chunk C at this point: chunk C + 1 (not while C == 0) and what has been requested of the image -
+            // its first half with chunk NC - 1 (ring slot 0 = that half of the image region is free from barrier NC - 3 on), its
+            // second half one barrier later
+            constexpr int behind = (C >= 1 && C + 1 < NC ? ST_PIECES : 0) + (C == NC - 2 ? ST_PIECES : 0) + (C == NC - 1 ? 2 * ST_PIECES : 0);
+            st_wait_vm<behind>();
+            fine_event(pf, w, lane, 220 + C);        // (diagnostics builds) this loader's part of chunk C has landed
+            lds_barrier();
+            fine_event(pf, w, lane, 210 + C);
+            if constexpr (C == 0) {
+                st_issue<st_slot(1, NC)>(lds0, chunk_src(1), hw, lane);
+                st_issue<st_slot(2, NC)>(lds0, chunk_src(2), hw, lane);
+            }
+            if constexpr (C == 1) st_wait_vm<ST_PIECES>();       // (chunk 1 before chunk 3 is requested: the count below assumes one chunk behind)
+            if constexpr (C >= 1 && C + 2 < NC) st_issue<st_slot(C + 2, NC)>(lds0, chunk_src(C + 2), hw, lane);
+            if constexpr (C == NC - 3) st_issue_image<0>(v, nx, hw, lane);
+            if constexpr (C == NC - 2) st_issue_image<1>(v, nx, hw, lane);
+        };
+        lstep(IC<0>{}); lstep(IC<1>{}); lstep(IC<2>{}); lstep(IC<3>{});
+        if constexpr (NC > 4) { lstep(IC<4>{}); lstep(IC<5>{}); }
+        if constexpr (NC > 6) { lstep(IC<6>{}); lstep(IC<7>{}); }
+        if constexpr (NC > 8) { lstep(IC<8>{}); lstep(IC<9>{}); }
+        fine_event(pf, w, lane, 240);
+        lds_barrier();                               // the ring is done
+        prof_event(pf, w, lane, 250);
+    } else {
     // ---- atom waves: what the epilogues add, requested ahead (vector memory returns in order)
+    // (here, not before the reduction of the slot partials - where the round trip would be free: 64..96 more live registers
+    // across it end up in scratch, +50 % on the whole phase, round 6)
     float4 t0r[8], hold[8], bb4[8];
     if (awave) {
         if constexpr (POST) {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, w, ot, lane);
+            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, wa, ot, lane);
 #pragma unroll
             for (int ot = 0; ot < 8; ++ot) {
-                hold[ot] = *st_tile(hs + HS_HT, w, ot, lane);
+                hold[ot] = *st_tile(hs + HS_HT, wa, ot, lane);
                 bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
             }
         } else {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, w, ot, lane);
+            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, wa, ot, lane);
         }
     }
     BOp bin, bout;                                   // the GEMM in flight reads `bin` and fills `bout`
@@ -1667,26 +1749,26 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
             }
         }
     }
-    // ---- the stream: one step per chunk.  Loaders: chunk C has landed -> barrier -> request chunk C + 2 (the slot of chunk
-    // C - 2 is free: every atom wave is past it) and, two chunks before the end, the next pair loop's image.
-    // Atom waves: barrier -> the four output tiles of chunk C -> their epilogue.
+    prof_event(pf, w, lane, 200);
+    // one step per chunk: barrier -> the four output tiles of chunk C -> their epilogue
     auto step = [&](auto C_) {
         constexpr int C = decltype(C_)::value;
-        if (loader) {
-            // outstanding behind chunk C at this point: chunk C + 1 (and C + 2 while C == 0), the image once requested
-            constexpr int behind = (C + 1 < NC ? ST_PIECES : 0) + (C == 0 && C + 2 < NC ? ST_PIECES : 0) + (C == NC - 1 ? ST_IMAGE_PIECES : 0);
-            st_wait_vm<behind>();
-        }
+        fine_event(pf, w, lane, 230 + C);            // (diagnostics builds) this wave is done with chunk C - 1
         lds_barrier();
-        if (loader) {
-            if constexpr (C >= 1 && C + 2 < NC) st_issue<st_slot(C + 2, NC)>(lds0, chunk_src(C + 2), hw, lane);
-            if constexpr (C == NC - 2) st_issue_image(v, nx, hw, lane);
-            return;
-        }
+        fine_event(pf, w, lane, 210 + C);
         if (!awave) return;
+        constexpr int half = C & 1;                  // tiles 4 half .. 4 half + 3 of the unit = k-slabs 2 half, 2 half + 1 of its result
+        // the bias of the chunk's four tiles (P: b1' / b5', T0: b3'), requested BEFORE its matrix instructions and before its
+        // stores: behind a store the compiler cannot prove disjoint it would wait for the store's completion first
+        constexpr bool IS_P = !(POST && C < 4) && C < C_P + 2, IS_T0 = C >= C_P + 4;
+        float4 bias[4];
+        if constexpr (IS_P || IS_T0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                bias[t] = *reinterpret_cast<const float4*>(vecn + (IS_T0 ? 4 * HID : 0) + 16 * (4 * half + t) + 4 * kg);
+        }
         if constexpr (POST && C == 0) st_load_rows(bin, lds0 + AGG_OFF, lc, kg, s_agg);
         st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
-        constexpr int half = C & 1;                  // tiles 4 half .. 4 half + 3 of the unit = k-slabs 2 half, 2 half + 1 of its result
         if constexpr (POST && C < 2) {
             // node MLP layer 1: t = SiLU(T0 + W3b' agg), times s_t 2^n_tile
 #pragma unroll
@@ -1715,7 +1797,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                     const float4 hd = hold[ot], b4 = bb4[ot];
                     const float hv[4] = {fmaf(acc[2 * sp + tt][0], inv2, hd.x + b4.x), fmaf(acc[2 * sp + tt][1], inv2, hd.y + b4.y),
                                          fmaf(acc[2 * sp + tt][2], inv2, hd.z + b4.z), fmaf(acc[2 * sp + tt][3], inv2, hd.w + b4.w)};
-                    *st_tile(hs + HS_HT, w, ot, lane) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+                    *st_tile(hs + HS_HT, wa, ot, lane) = make_float4(hv[0], hv[1], hv[2], hv[3]);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         u[4 * tt + i] = hv[i] * s_hn;
@@ -1728,16 +1810,16 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 bin = bout;
                 block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
             }
-        } else if constexpr (C < C_P + 2) {
+        } else if constexpr (IS_P) {
             // P = W1a' h + b1 (W5a' h + b5): kept in registers until the ring has let go of the P region
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int ot = 4 * half + t, nt = ot >> 1;
                 const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + nt));
-                const float4 b1 = *reinterpret_cast<const float4*>(vecn + 16 * ot + 4 * kg);
+                const float4 b1 = bias[t];
                 Pout[ot] = make_float4(fmaf(acc[t][0], inv, b1.x), fmaf(acc[t][1], inv, b1.y), fmaf(acc[t][2], inv, b1.z), fmaf(acc[t][3], inv, b1.w));
             }
-        } else if constexpr (C < C_P + 4) {
+        } else if constexpr (!IS_T0) {
             // Q = W1b' h (W5b' h), times the geometric scale S1 (a team applies its own after the exchange)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -1751,8 +1833,8 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
             for (int t = 0; t < 4; ++t) {
                 const int ot = 4 * half + t, nt = ot >> 1;
                 const float inv = inv_pow2(s_hf * cload(scn, GS_SW_W3A + nt));
-                const float4 b3 = *reinterpret_cast<const float4*>(vecn + 4 * HID + 16 * ot + 4 * kg);
-                *st_tile(hs + HS_T0, w, ot, lane) = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y),
+                const float4 b3 = bias[t];
+                *st_tile(hs + HS_T0, wa, ot, lane) = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y),
                                                                 fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
             }
         }
@@ -1761,13 +1843,16 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     if constexpr (NC > 4) { step(IC<4>{}); step(IC<5>{}); }
     if constexpr (NC > 6) { step(IC<6>{}); step(IC<7>{}); }
     if constexpr (NC > 8) { step(IC<8>{}); step(IC<9>{}); }
+    fine_event(pf, w, lane, 240);
     lds_barrier();                                   // the ring is done: the P and Q regions are free
+    prof_event(pf, w, lane, 250);
     if (valid) {
 #pragma unroll
         for (int ot = 0; ot < 8; ++ot) {
             *reinterpret_cast<float4*>(v.A + l * LDH + 16 * ot + 4 * kg) = Pout[ot];
             *reinterpret_cast<float4*>(v.B + l * LDH + 16 * ot + 4 * kg) = Qout[ot];
         }
+    }
     }
     if (tid == 0) {
         if constexpr (POST) { v.fmax[FS_HS] = __float_as_uint(s_hn); v.misc[CX_PAR] = par ^ 1; }

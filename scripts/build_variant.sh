@@ -1,10 +1,11 @@
 #!/bin/bash
-# A/B builds of the HIP library: scripts/build_variant.sh NAME [extra hipcc flags]  ->  build/lib_NAME.so
-# (select it with DIFFLINKER_HIP_LIB=build/lib_NAME.so; build/ travels to the GPU box with the snapshot)
+# A/B builds of the HIP library: scripts/build_variant.sh NAME [extra hipcc flags]  ->  difflinker_amd/variants/lib_NAME.so
+# (select it with DIFFLINKER_HIP_LIB=difflinker_amd/variants/lib_NAME.so; *.so is git-ignored but travels to the GPU box with
+# the snapshot - build/ does not)
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
-mkdir -p build/obj_$name
+mkdir -p build/obj_$name difflinker_amd/variants
 objs=""
 for f in egnn_fc egnn_sparse size_gnn; do
   extra=""; [ $f = egnn_fc ] && extra="-mllvm -amdgpu-sched-strategy=iterative-ilp"
@@ -13,6 +14,6 @@ for f in egnn_fc egnn_sparse size_gnn; do
   objs="$objs build/obj_$name/$f.o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o build/lib_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o difflinker_amd/variants/lib_$name.so
 rm -rf build/obj_$name
-ls -la build/lib_$name.so
+ls -la difflinker_amd/variants/lib_$name.so

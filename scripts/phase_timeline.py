@@ -46,8 +46,14 @@ z = torch.cat([inp['x'], inp['h']], 2) * inp['fragment_mask'] + torch.randn(B, N
 t = torch.full((B, 1), 0.5, device=dev)
 args = dict(t=t, xh=z, node_mask=inp['node_mask'], linker_mask=inp['linker_mask'], edge_mask=inp['edge_mask'],
             context=inp['context'])
-for _ in range(3):
-    dyn.forward(**args)
+try:
+    for _ in range(3):
+        dyn.forward(**args)
+except Exception as e:      # knock-out builds produce NaNs: the raw launch instead
+    print('note:', type(e).__name__)
+    dyn.forward = lambda **kw: dyn._launch_forward(kw['t'], kw['xh'], kw['node_mask'], kw['linker_mask'], kw['edge_mask'], kw['context'])
+    for _ in range(3):
+        dyn.forward(**args)
 torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ev0.record()
@@ -75,6 +81,18 @@ names = {(12, 120): 'gcl: PAIR loop, this wave', (120, 13): 'gcl: wait for the o
          (105, 15): 'gcl: mlp1 epilogue', (14, 105): 'gcl: mlp1 frags + both gemms', (15, 106): 'gcl: barrier + mlp2 residual loads', (106, 107): 'gcl: mlp2 gemm',
          (107, 16): 'gcl: mlp2 epilogue (LDS + HBM rows)', (10, 110): 'open: projections P, Q, T0', (110, 111): 'open: barrier + exchange stores',
          (111, 112): 'open: team sync (drain, barrier, flags)', (112, 11): 'open: exchange loads -> LDS', (22, 23): 'gcl: W2\' DMA issue + agg fragment rows', (23, 14): 'gcl: barrier (agg in place)'}
+# per-atom phases version 3 (stream_phase): 200 = stream begins, 210 + C = chunk C landed and published, 240 = last chunk computed,
+# 250 = ring done
+for pre_, nm_ in ((22, 'v3 post: agg rows, scales, first DMA issue'), (10, 'v3 open: first DMA issue, h -> fragments'), (2, 'v3 entry: first DMA issue, h -> fragments')):
+    names[(pre_, 200)] = nm_
+names[(200, 210)] = 'v3: wait for chunk 0 (+ barrier)'
+for c_ in range(10):
+    names[(210 + c_, 211 + c_)] = f'v3: chunk {c_} (mfma + epilogue; loaders: wait) + barrier'
+    names[(210 + c_, 240)] = f'v3: last chunk ({c_})'
+names[(240, 250)] = 'v3: ring-done barrier'
+names[(250, 11)] = 'v3: P, Q rows -> LDS'
+names[(250, 110)] = 'v3: P, Q rows -> LDS'
+names[(11, 32)] = 'gcl: barrier'
 inloop = {(40, 41): 'L1 (geo, SiLU, split)', (41, 42): 'M0 (48 mfma)', (42, 43): 'E0 (epilogue)', (43, 44): 'M1 (48 mfma)',
           (44, 45): 'E1 (epilogue)'}
 for w in range(8):
@@ -82,6 +100,23 @@ for w in range(8):
     n = int((e[:, 0] != 0).sum())
     tags = [int(x) for x in e[:n, 0]]
     ts = [int(x) for x in e[:n, 1]]
+    if 200 in tags:
+        # raw event log of the stream phases of passes 0..2 (tag:ticks since the phase's first event)
+        seen = 0
+        k = 0
+        while k < n and seen < (4 if w in (0, 4) else 2):
+            if tags[k] == 200:
+                j = k
+                while j + 1 < n and tags[j + 1] >= 200:
+                    j += 1
+                print(f'   wave {w} stream phase {seen}: ' + ' '.join(f'{tags[i]}:{ts[i] - ts[k]}' for i in range(k, j + 1)) + f' | next {tags[j + 1] if j + 1 < n else None}:{(ts[j + 1] - ts[k]) if j + 1 < n else None}')
+                seen += 1
+                k = j
+            k += 1
+    # (the fine-grained tags 220.. / 230.. are for the raw log only)
+    keep = [i for i in range(n) if not (220 <= tags[i] < 240)]
+    tags, ts = [tags[i] for i in keep], [ts[i] for i in keep]
+    n = len(tags)
     # pass-level events only (tags < 40), in-loop events (40..45) of step 2 reported separately per pass kind
     top = [(tg, t_) for tg, t_ in zip(tags, ts) if tg < 40 or tg >= 100]
     tot = collections.OrderedDict()
@@ -126,6 +161,19 @@ for w in range(8):
             first.append((tg, t_))
         line = ' '.join(f'{tg}:{t_ - first[0][1]}' for tg, t_ in first)
         print(f'   wave {w} segment log (tag:ticks since first): {line}')
+    # per-atom time: from the end of a pair loop (13 / 33: partials written) to the start of the next (12 / 32) or the head (3)
+    per_atom = {'after gcl': [], 'after eq': []}
+    start = None
+    for tg, t_ in zip(tags, ts):
+        if tg in (13, 33):
+            start = (tg, t_)
+        elif tg in (12, 32, 3) and start is not None:
+            per_atom['after gcl' if start[0] == 13 else 'after eq'].append(t_ - start[1])
+            start = None
+    if w in (0, 4):
+        for k_, v_ in per_atom.items():
+            if v_:
+                print(f'   wave {w} per-atom phases {k_}: {len(v_)} x mean {sum(v_) // len(v_)} ticks (min {min(v_)}, max {max(v_)}); sum {sum(v_)} = {100.0 * sum(v_) / max(total, 1):.1f} % of the forward')
     print(f'wave {w}: gcl PAIR {tot.get("gcl: PAIR loop + partials", 0):9d}  eq PAIR {tot.get("eq: PAIR loop + partials", 0):9d}  total {total}')
     if w in (0, 4, 7):
         print(f'--- wave {w}: {n} events, total {total} ticks')
