@@ -75,7 +75,8 @@ static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) 
 // weight ring (the first 64 KB from L_A, and the W2' region) - the loaders start as soon as the pair loop is over
 constexpr int L_TRIP3 = L_A + 2 * ST_CHUNK;        // slot triples [256][4]
 constexpr int L_AGGX3 = L_TRIP3 + 4 * 256;         // coordinate aggregate of the own atoms [55][4]
-static_assert(L_AGGX3 + 4 * (NMAX + 1) <= L_W && (L_TRIP3 % 4) == 0, "version-3 coordinate scratch must fit the h region");
+constexpr int L_XCH3 = L_AGGX3 + 4 * (NMAX + 1);   // result tiles that the waves sharing a 16-atom tile hand round: [2 tiles][8][64] float4
+static_assert(L_XCH3 + 2 * 8 * 256 <= L_W && (L_TRIP3 % 4) == 0 && (L_XCH3 % 4) == 0, "version-3 scratch must fit the h region behind the ring");
 
 // Team kernels (several workgroups share one molecule, see team_sync): words of v.misc.  Everything a team member needs
 // is re-read from here at the point of use, so nothing of it lives in registers across the pair loops.
@@ -1548,6 +1549,23 @@ __device__ __forceinline__ void st_mma_chunk(const float* lds0, const BOp& b, fl
 #endif
     }
 }
+// one output tile (t of the chunk's four) alone - a wave that shares its atoms' tile with others (stream_phase: wpt > 1): the
+// twelve MFMAs form ONE dependent chain per accumulator, so the k-slabs alternate between two partial accumulators
+template <int SLOT>
+__device__ __forceinline__ floatx4 st_mma_tile(const float* lds0, const BOp& b, int t, int lane) {
+    const uint4* Wc = reinterpret_cast<const uint4*>(lds0 + st_slot_off(SLOT)) + lane + t * (4 * 2 * 64);
+    floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+    uint4 ah[4], al[4];
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) { ah[sl] = Wc[(sl * 2 + 0) * 64]; al[sl] = Wc[(sl * 2 + 1) * 64]; }
+#pragma unroll
+    for (int sl = 0; sl < 4; sl += 2) {
+        a0 = mfma16(al[sl], b.hi[sl], a0);         a1 = mfma16(al[sl + 1], b.hi[sl + 1], a1);
+        a0 = mfma16(ah[sl], b.lo[sl], a0);         a1 = mfma16(ah[sl + 1], b.lo[sl + 1], a1);
+        a0 = mfma16(ah[sl], b.hi[sl], a0);         a1 = mfma16(ah[sl + 1], b.hi[sl + 1], a1);
+    }
+    return a0 + a1;
+}
 // loader waves: chunk `src` (32 KB, global) -> ring slot SLOT, 8 pieces of 1 KB per wave
 template <int SLOT>
 __device__ __forceinline__ void st_issue(float* lds0, const float* __restrict__ src, int hw, int lane) {
@@ -1639,10 +1657,21 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     const int hw = w - ST_AWAVES, wa = w;
 #endif
     const int n = lane & 15, kg = lane >> 4;
-    const int l = 16 * wa + n;                                           // own atom of this lane (atom waves)
-    const bool awave = !loader && 16 * wa < nown;                        // wave-uniform
+    // A workgroup with few own atoms (a team member; a small molecule) has fewer 16-atom tiles than atom waves: its 1 or 2
+    // tiles are then shared by 4 or 2 waves each, which split the OUTPUT TILES of every chunk between them (wave `part` of a
+    // tile takes tiles part, part + wpt, ... of the four) and hand the results round through LDS (XCH) - a quarter / half of
+    // the matrix instructions and weight-fragment reads per wave (round 6: a team member used to run the whole chain on one
+    // wave while three idled)
+    const int ntile = (nown + 15) >> 4;                                  // 16-atom tiles of this workgroup: 1..4
+    const int wpt = ntile >= 3 ? 1 : (ntile == 2 ? 2 : 4);               // atom waves per tile
+    const int ta = wpt == 1 ? wa : (wpt == 2 ? (wa & 1) : 0);            // this wave's tile
+    const int part = wpt == 1 ? 0 : (wpt == 2 ? (wa >> 1) : wa);         // ... and which of the tile's waves it is
+    const int own = wpt == 1 ? 0xF : (wpt == 2 ? (0x5 << part) : (1 << part));     // output tiles of a chunk this wave computes
+    const int l = 16 * ta + n;                                           // own atom of this lane (atom waves)
+    const bool awave = !loader && 16 * ta < nown;                        // wave-uniform
     const bool valid = awave && l < nown;
     const int lc = max(min(l, nown - 1), 0);
+    float* xch = lds0 + L_XCH3 + ta * (8 * 256);                         // [tile of the GEMM][lane] float4 (wpt > 1)
     auto chunk_src = [&](int c) -> const float* {                        // chunk c of this phase's stream (global)
         if (POST && c < 4) return g + G_ST_POST + c * ST_CHUNK;
         return nxb + (NEXT_EQ ? E_ST_PRE : G_ST_PRE) + (c - C_P) * ST_CHUNK;
@@ -1718,15 +1747,17 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     if (awave) {
         if constexpr (POST) {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, wa, ot, lane);
+            for (int ot = 0; ot < 8; ++ot)
+                if (own & (1 << (ot & 3))) t0r[ot] = *st_tile(hs + HS_T0, ta, ot, lane);
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) {
-                hold[ot] = *st_tile(hs + HS_HT, wa, ot, lane);
-                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
-            }
+            for (int ot = 0; ot < 8; ++ot)
+                if (own & (1 << (ot & 3))) {
+                    hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
+                    bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
+                }
         } else {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, wa, ot, lane);
+            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);     // (the B operand: every tile)
         }
     }
     BOp bin, bout;                                   // the GEMM in flight reads `bin` and fills `bout`
@@ -1750,7 +1781,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         }
     }
     prof_event(pf, w, lane, 200);
-    // one step per chunk: barrier -> the four output tiles of chunk C -> their epilogue
+    // one step per chunk: barrier -> the output tiles of chunk C (all four, or this wave's share) -> their epilogue
     auto step = [&](auto C_) {
         constexpr int C = decltype(C_)::value;
         fine_event(pf, w, lane, 230 + C);            // (diagnostics builds) this wave is done with chunk C - 1
@@ -1758,9 +1789,25 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         fine_event(pf, w, lane, 210 + C);
         if (!awave) return;
         constexpr int half = C & 1;                  // tiles 4 half .. 4 half + 3 of the unit = k-slabs 2 half, 2 half + 1 of its result
-        // the bias of the chunk's four tiles (P: b1' / b5', T0: b3'), requested BEFORE its matrix instructions and before its
-        // stores: behind a store the compiler cannot prove disjoint it would wait for the store's completion first
+        constexpr bool IS_MLP1 = POST && C < 2, IS_MLP2 = POST && C >= 2 && C < 4;
         constexpr bool IS_P = !(POST && C < 4) && C < C_P + 2, IS_T0 = C >= C_P + 4;
+        // shared tiles: the B-operand slabs of the PREVIOUS chunk, whose tiles the waves of this tile left in XCH behind the
+        // barrier above (every wave reads them before the next barrier; the slots are rewritten behind that one at the earliest)
+        if constexpr (POST && C >= 1 && C <= 4) {
+            if (wpt > 1) {
+                constexpr int hp = (C - 1) & 1;
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const float4 a = *reinterpret_cast<const float4*>(xch + ((4 * hp + 2 * sp) * 64 + lane) * 4);
+                    const float4 c4 = *reinterpret_cast<const float4*>(xch + ((4 * hp + 2 * sp + 1) * 64 + lane) * 4);
+                    const float u[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+                    split8t(u, bout.hi[2 * hp + sp], bout.lo[2 * hp + sp]);
+                }
+                if constexpr (hp == 1) bin = bout;
+            }
+        }
+        // the bias of the chunk's tiles (P: b1' / b5', T0: b3'), requested BEFORE its matrix instructions and before its
+        // stores: behind a store the compiler cannot prove disjoint it would wait for the store's completion first
         float4 bias[4];
         if constexpr (IS_P || IS_T0) {
 #pragma unroll
@@ -1768,75 +1815,65 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 bias[t] = *reinterpret_cast<const float4*>(vecn + (IS_T0 ? 4 * HID : 0) + 16 * (4 * half + t) + 4 * kg);
         }
         if constexpr (POST && C == 0) st_load_rows(bin, lds0 + AGG_OFF, lc, kg, s_agg);
-        st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
-        if constexpr (POST && C < 2) {
-            // node MLP layer 1: t = SiLU(T0 + W3b' agg), times s_t 2^n_tile
+        if (wpt == 1) st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
+        else {
 #pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                float u[8];
+            for (int t = 0; t < 4; ++t)
+                if (own & (1 << t)) acc[t] = st_mma_tile<st_slot(C, NC)>(lds0, bin, t, lane);
+        }
+        // epilogue of tile t of the chunk: the four values of this lane (features 16 ot + 4 kg + 0..3 of its atom)
+        float4 res[4];
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int ot = 4 * half + 2 * sp + tt, nt = ot >> 1;
-                    const float inv = inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)), stn = s_t * cload(sc, GS_NT + nt);
-                    const float4 t0 = t0r[ot];
-                    const float t0v[4] = {t0.x, t0.y, t0.z, t0.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) u[4 * tt + i] = silu_u(fmaf(acc[2 * sp + tt][i], inv, t0v[i])) * stn;
-                }
-                split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
-            }
-            if constexpr (C == 1) bin = bout;
-        } else if constexpr (POST && C < 4) {
-            // node MLP layer 2 + residual: the new h -> HBM scratch (fp32), max |h|, B operand of the projections
-#pragma unroll
-            for (int sp = 0; sp < 2; ++sp) {
-                float u[8];
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    const int ot = 4 * half + 2 * sp + tt;
-                    const float4 hd = hold[ot], b4 = bb4[ot];
-                    const float hv[4] = {fmaf(acc[2 * sp + tt][0], inv2, hd.x + b4.x), fmaf(acc[2 * sp + tt][1], inv2, hd.y + b4.y),
-                                         fmaf(acc[2 * sp + tt][2], inv2, hd.z + b4.z), fmaf(acc[2 * sp + tt][3], inv2, hd.w + b4.w)};
-                    *st_tile(hs + HS_HT, wa, ot, lane) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        u[4 * tt + i] = hv[i] * s_hn;
-                        hm = fmaxf(hm, valid ? fabsf(hv[i]) : 0.0f);
-                    }
-                }
-                split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
-            }
-            if constexpr (C == 3) {
-                bin = bout;
-                block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
-            }
-        } else if constexpr (IS_P) {
-            // P = W1a' h + b1 (W5a' h + b5): kept in registers until the ring has let go of the P region
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ot = 4 * half + t, nt = ot >> 1;
+        for (int t = 0; t < 4; ++t) {
+            if (wpt > 1 && !(own & (1 << t))) continue;
+            const int ot = 4 * half + t, nt = ot >> 1;
+            if constexpr (IS_MLP1) {
+                // node MLP layer 1: t = SiLU(T0 + W3b' agg), times s_t 2^n_tile
+                const float inv = inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)), stn = s_t * cload(sc, GS_NT + nt);
+                const float4 t0 = t0r[ot];
+                res[t] = make_float4(silu_u(fmaf(acc[t][0], inv, t0.x)) * stn, silu_u(fmaf(acc[t][1], inv, t0.y)) * stn,
+                                     silu_u(fmaf(acc[t][2], inv, t0.z)) * stn, silu_u(fmaf(acc[t][3], inv, t0.w)) * stn);
+            } else if constexpr (IS_MLP2) {
+                // node MLP layer 2 + residual: the new h -> HBM scratch (fp32), max |h|, B operand of the projections
+                const float4 hd = hold[ot], b4 = bb4[ot];
+                const float4 hv = make_float4(fmaf(acc[t][0], inv2, hd.x + b4.x), fmaf(acc[t][1], inv2, hd.y + b4.y),
+                                              fmaf(acc[t][2], inv2, hd.z + b4.z), fmaf(acc[t][3], inv2, hd.w + b4.w));
+                *st_tile(hs + HS_HT, ta, ot, lane) = hv;
+                if (valid) hm = fmaxf(fmaxf(hm, fmaxf(fabsf(hv.x), fabsf(hv.y))), fmaxf(fabsf(hv.z), fabsf(hv.w)));
+                res[t] = make_float4(hv.x * s_hn, hv.y * s_hn, hv.z * s_hn, hv.w * s_hn);
+            } else if constexpr (IS_P) {
+                // P = W1a' h + b1 (W5a' h + b5): kept in registers until the ring has let go of the P region
                 const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + nt));
                 const float4 b1 = bias[t];
                 Pout[ot] = make_float4(fmaf(acc[t][0], inv, b1.x), fmaf(acc[t][1], inv, b1.y), fmaf(acc[t][2], inv, b1.z), fmaf(acc[t][3], inv, b1.w));
-            }
-        } else if constexpr (!IS_T0) {
-            // Q = W1b' h (W5b' h), times the geometric scale S1 (a team applies its own after the exchange)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ot = 4 * half + t, nt = ot >> 1;
+            } else if constexpr (!IS_T0) {
+                // Q = W1b' h (W5b' h), times the geometric scale S1 (a team applies its own after the exchange)
                 const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + 4 + nt)) * S1;
                 Qout[ot] = make_float4(acc[t][0] * inv, acc[t][1] * inv, acc[t][2] * inv, acc[t][3] * inv);
-            }
-        } else {
-            // T0 = W3a' h + b3 of the GCL being opened -> HBM scratch
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int ot = 4 * half + t, nt = ot >> 1;
+            } else {
+                // T0 = W3a' h + b3 of the GCL being opened -> HBM scratch
                 const float inv = inv_pow2(s_hf * cload(scn, GS_SW_W3A + nt));
                 const float4 b3 = bias[t];
-                *st_tile(hs + HS_T0, wa, ot, lane) = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y),
-                                                                fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
+                *st_tile(hs + HS_T0, ta, ot, lane) = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y),
+                                                                 fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
             }
+        }
+        if constexpr (IS_MLP1 || IS_MLP2) {
+            // the chunk's results as the next GEMM's B operand: k-slabs 2 half, 2 half + 1
+            if (wpt == 1) {
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    const float4 a = res[2 * sp], c4 = res[2 * sp + 1];
+                    const float u[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+                    split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
+                }
+                if constexpr (half == 1) bin = bout;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (own & (1 << t)) *reinterpret_cast<float4*>(xch + ((4 * half + t) * 64 + lane) * 4) = res[t];
+            }
+            if constexpr (C == 3) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
         }
     };
     step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
@@ -1848,10 +1885,11 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     prof_event(pf, w, lane, 250);
     if (valid) {
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot) {
-            *reinterpret_cast<float4*>(v.A + l * LDH + 16 * ot + 4 * kg) = Pout[ot];
-            *reinterpret_cast<float4*>(v.B + l * LDH + 16 * ot + 4 * kg) = Qout[ot];
-        }
+        for (int ot = 0; ot < 8; ++ot)
+            if (own & (1 << (ot & 3))) {
+                *reinterpret_cast<float4*>(v.A + l * LDH + 16 * ot + 4 * kg) = Pout[ot];
+                *reinterpret_cast<float4*>(v.B + l * LDH + 16 * ot + 4 * kg) = Qout[ot];
+            }
     }
     }
     if (tid == 0) {
