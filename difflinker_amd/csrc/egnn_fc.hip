@@ -75,8 +75,7 @@ static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) 
 // weight ring (the first 64 KB from L_A, and the W2' region) - the loaders start as soon as the pair loop is over
 constexpr int L_TRIP3 = L_A + 2 * ST_CHUNK;        // slot triples [256][4]
 constexpr int L_AGGX3 = L_TRIP3 + 4 * 256;         // coordinate aggregate of the own atoms [55][4]
-constexpr int L_XCH3 = L_AGGX3 + 4 * (NMAX + 1);   // result tiles that the waves sharing a 16-atom tile hand round: [2 tiles][8][64] float4
-static_assert(L_XCH3 + 2 * 8 * 256 <= L_W && (L_TRIP3 % 4) == 0 && (L_XCH3 % 4) == 0, "version-3 scratch must fit the h region behind the ring");
+static_assert(L_AGGX3 + 4 * (NMAX + 1) <= L_W && (L_TRIP3 % 4) == 0, "version-3 coordinate scratch must fit the h region behind the ring");
 
 // Team kernels (several workgroups share one molecule, see team_sync): words of v.misc.  Everything a team member needs
 // is re-read from here at the point of use, so nothing of it lives in registers across the pair loops.
@@ -87,6 +86,7 @@ constexpr int TM_FLAGS = 6;      // arrival words of this molecule's workgroups 
 constexpr int TM_S = 8, TM_RANK = 9, TM_NOWN = 10;   // team size, own index, number of own atoms (one workgroup: 1, 0, n_b)
 constexpr int MS_NRCV = 12;      // (every kernel) length of the coordinate-pass receiver list v.rcv
 constexpr int MS_FULL = 13;      // (every kernel) the receiver list holds EVERY own atom (no linker mask, or a skipped sum could not be proven finite)
+constexpr int CX_V3 = 38;        // (pass context, below) this workgroup runs the per-atom phases version 3: see forward_molecule2
 
 struct Lds {
     float *A, *B, *C, *W, *vec, *xs, *x0, *aggx, *z, *lm, *frag;
@@ -721,9 +721,9 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                     *reinterpret_cast<float4*>(pb + 32 * mt + 8 * qq + 4 * hh) =
                         make_float4(agg[mt][4 * qq], agg[mt][4 * qq + 1], agg[mt][4 * qq + 2], agg[mt][4 * qq + 3]);
         } else if (hh == 0) {
-            // compact [slot][4] triples inside the P region: H (v.C) must survive a coordinate pass (f16 modes, round 6:
+            // compact [slot][4] triples inside the P region: H (v.C) must survive a coordinate pass (per-atom phases version 3:
             // behind the weight ring of stream_phase, whose loaders start as soon as the loop is over)
-            *reinterpret_cast<float4*>(v.A + (PREC != 0 ? L_TRIP3 - L_A : 0) + 4 * slot) = make_float4(ax, ay, az, 0.0f);
+            *reinterpret_cast<float4*>(v.A + (v.misc[CX_V3] != 0 ? L_TRIP3 - L_A : 0) + 4 * slot) = make_float4(ax, ay, az, 0.0f);
         }
     }
 }
@@ -918,8 +918,8 @@ constexpr int SCE_L1_W5A = 8, SCE_L1_W5B = 9, SCE_B5 = 10;
 // round 3: ten such reloads in the 2 us reduction alone.
 constexpr int CX_N = 16, CX_EM = 17, CX_HS = 19, CX_WP = 21, CX_PASS = 23, CX_PAR = 24, CX_FLAGS = 25, CX_NORMC = 26,
               CX_CRANGE = 27, CX_INVNORM = 28, CX_NPASS = 29, CX_NF = 30, CX_FIN = 31, CX_TFEAT = 32, CX_MOL = 33, CX_CTXP = 34,
-              CX_SUB = 36, CX_CT = 37;      // inv_sublayers (GCLs per block), condition_time
-static_assert(CX_CT < MISC_WORDS, "context block");
+              CX_SUB = 36, CX_CT = 37;      // inv_sublayers (GCLs per block), condition_time; [38] CX_V3 (above)
+static_assert(CX_CT < CX_V3 && CX_V3 < MISC_WORDS, "context block");
 __device__ __forceinline__ int ctx_i(const Lds& v, int k) {
     typedef volatile __attribute__((address_space(3))) int* lds_vint_t;       // a plain ds_read_b32 (a volatile GENERIC access is a flat sc0 sc1 load)
     return __builtin_amdgcn_readfirstlane(*(lds_vint_t)(v.misc + k));
@@ -1549,23 +1549,6 @@ __device__ __forceinline__ void st_mma_chunk(const float* lds0, const BOp& b, fl
 #endif
     }
 }
-// one output tile (t of the chunk's four) alone - a wave that shares its atoms' tile with others (stream_phase: wpt > 1): the
-// twelve MFMAs form ONE dependent chain per accumulator, so the k-slabs alternate between two partial accumulators
-template <int SLOT>
-__device__ __forceinline__ floatx4 st_mma_tile(const float* lds0, const BOp& b, int t, int lane) {
-    const uint4* Wc = reinterpret_cast<const uint4*>(lds0 + st_slot_off(SLOT)) + lane + t * (4 * 2 * 64);
-    floatx4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-    uint4 ah[4], al[4];
-#pragma unroll
-    for (int sl = 0; sl < 4; ++sl) { ah[sl] = Wc[(sl * 2 + 0) * 64]; al[sl] = Wc[(sl * 2 + 1) * 64]; }
-#pragma unroll
-    for (int sl = 0; sl < 4; sl += 2) {
-        a0 = mfma16(al[sl], b.hi[sl], a0);         a1 = mfma16(al[sl + 1], b.hi[sl + 1], a1);
-        a0 = mfma16(ah[sl], b.lo[sl], a0);         a1 = mfma16(ah[sl + 1], b.lo[sl + 1], a1);
-        a0 = mfma16(ah[sl], b.hi[sl], a0);         a1 = mfma16(ah[sl + 1], b.hi[sl + 1], a1);
-    }
-    return a0 + a1;
-}
 // loader waves: chunk `src` (32 KB, global) -> ring slot SLOT, 8 pieces of 1 KB per wave
 template <int SLOT>
 __device__ __forceinline__ void st_issue(float* lds0, const float* __restrict__ src, int hw, int lane) {
@@ -1578,20 +1561,6 @@ __device__ __forceinline__ void st_issue(float* lds0, const float* __restrict__ 
 #pragma unroll
     for (int it = 0; it < ST_PIECES; ++it) {
         const int piece = it * 4 + hw;
-        __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(lds0 + st_slot_off(SLOT) + piece * 256), 16, 0, 0);
-    }
-#endif
-}
-// every wave: its eighth of a chunk (the first chunk of a stream)
-template <int SLOT>
-__device__ __forceinline__ void st_issue8(float* lds0, const float* __restrict__ src, int w, int lane) {
-    typedef const __attribute__((address_space(1))) void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    const float4* s4 = reinterpret_cast<const float4*>(src) + lane;
-#ifndef DL_KO_DMA
-#pragma unroll
-    for (int it = 0; it < ST_PIECES / 2; ++it) {
-        const int piece = it * 8 + w;
         __builtin_amdgcn_global_load_lds((gptr_t)(s4 + piece * 64), (lptr_t)(lds0 + st_slot_off(SLOT) + piece * 256), 16, 0, 0);
     }
 #endif
@@ -1657,21 +1626,16 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     const int hw = w - ST_AWAVES, wa = w;
 #endif
     const int n = lane & 15, kg = lane >> 4;
-    // A workgroup with few own atoms (a team member; a small molecule) has fewer 16-atom tiles than atom waves: its 1 or 2
-    // tiles are then shared by 4 or 2 waves each, which split the OUTPUT TILES of every chunk between them (wave `part` of a
-    // tile takes tiles part, part + wpt, ... of the four) and hand the results round through LDS (XCH) - a quarter / half of
-    // the matrix instructions and weight-fragment reads per wave (round 6: a team member used to run the whole chain on one
-    // wave while three idled)
-    const int ntile = (nown + 15) >> 4;                                  // 16-atom tiles of this workgroup: 1..4
-    const int wpt = ntile >= 3 ? 1 : (ntile == 2 ? 2 : 4);               // atom waves per tile
-    const int ta = wpt == 1 ? wa : (wpt == 2 ? (wa & 1) : 0);            // this wave's tile
-    const int part = wpt == 1 ? 0 : (wpt == 2 ? (wa >> 1) : wa);         // ... and which of the tile's waves it is
-    const int own = wpt == 1 ? 0xF : (wpt == 2 ? (0x5 << part) : (1 << part));     // output tiles of a chunk this wave computes
+    // (tried, round 6: a workgroup with one or two 16-atom tiles - a team member, a small molecule - sharing each tile between 4 / 2
+    // waves that split the output tiles of a chunk and hand the results round through LDS: a quarter / half of the matrix
+    // instructions per wave, measured NEUTRAL - with so little matrix work a step is a chain of latencies (barrier, fragment
+    // reads, a dependent MFMA chain, the hand-over), 1.4 K cycles whatever its size.  Such workgroups keep version 2: see
+    // forward_molecule2)
+    const int ta = wa;                                                   // this wave's 16-atom tile
     const int l = 16 * ta + n;                                           // own atom of this lane (atom waves)
     const bool awave = !loader && 16 * ta < nown;                        // wave-uniform
     const bool valid = awave && l < nown;
     const int lc = max(min(l, nown - 1), 0);
-    float* xch = lds0 + L_XCH3 + ta * (8 * 256);                         // [tile of the GEMM][lane] float4 (wpt > 1)
     auto chunk_src = [&](int c) -> const float* {                        // chunk c of this phase's stream (global)
         if (POST && c < 4) return g + G_ST_POST + c * ST_CHUNK;
         return nxb + (NEXT_EQ ? E_ST_PRE : G_ST_PRE) + (c - C_P) * ST_CHUNK;
@@ -1747,17 +1711,15 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     if (awave) {
         if constexpr (POST) {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot)
-                if (own & (1 << (ot & 3))) t0r[ot] = *st_tile(hs + HS_T0, ta, ot, lane);
+            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, ta, ot, lane);
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot)
-                if (own & (1 << (ot & 3))) {
-                    hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
-                    bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
-                }
+            for (int ot = 0; ot < 8; ++ot) {
+                hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
+                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
+            }
         } else {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);     // (the B operand: every tile)
+            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
         }
     }
     BOp bin, bout;                                   // the GEMM in flight reads `bin` and fills `bout`
@@ -1791,21 +1753,6 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         constexpr int half = C & 1;                  // tiles 4 half .. 4 half + 3 of the unit = k-slabs 2 half, 2 half + 1 of its result
         constexpr bool IS_MLP1 = POST && C < 2, IS_MLP2 = POST && C >= 2 && C < 4;
         constexpr bool IS_P = !(POST && C < 4) && C < C_P + 2, IS_T0 = C >= C_P + 4;
-        // shared tiles: the B-operand slabs of the PREVIOUS chunk, whose tiles the waves of this tile left in XCH behind the
-        // barrier above (every wave reads them before the next barrier; the slots are rewritten behind that one at the earliest)
-        if constexpr (POST && C >= 1 && C <= 4) {
-            if (wpt > 1) {
-                constexpr int hp = (C - 1) & 1;
-#pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const float4 a = *reinterpret_cast<const float4*>(xch + ((4 * hp + 2 * sp) * 64 + lane) * 4);
-                    const float4 c4 = *reinterpret_cast<const float4*>(xch + ((4 * hp + 2 * sp + 1) * 64 + lane) * 4);
-                    const float u[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
-                    split8t(u, bout.hi[2 * hp + sp], bout.lo[2 * hp + sp]);
-                }
-                if constexpr (hp == 1) bin = bout;
-            }
-        }
         // the bias of the chunk's tiles (P: b1' / b5', T0: b3'), requested BEFORE its matrix instructions and before its
         // stores: behind a store the compiler cannot prove disjoint it would wait for the store's completion first
         float4 bias[4];
@@ -1815,17 +1762,11 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 bias[t] = *reinterpret_cast<const float4*>(vecn + (IS_T0 ? 4 * HID : 0) + 16 * (4 * half + t) + 4 * kg);
         }
         if constexpr (POST && C == 0) st_load_rows(bin, lds0 + AGG_OFF, lc, kg, s_agg);
-        if (wpt == 1) st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
-        else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (own & (1 << t)) acc[t] = st_mma_tile<st_slot(C, NC)>(lds0, bin, t, lane);
-        }
+        st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
         // epilogue of tile t of the chunk: the four values of this lane (features 16 ot + 4 kg + 0..3 of its atom)
         float4 res[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            if (wpt > 1 && !(own & (1 << t))) continue;
             const int ot = 4 * half + t, nt = ot >> 1;
             if constexpr (IS_MLP1) {
                 // node MLP layer 1: t = SiLU(T0 + W3b' agg), times s_t 2^n_tile
@@ -1860,19 +1801,13 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         }
         if constexpr (IS_MLP1 || IS_MLP2) {
             // the chunk's results as the next GEMM's B operand: k-slabs 2 half, 2 half + 1
-            if (wpt == 1) {
 #pragma unroll
-                for (int sp = 0; sp < 2; ++sp) {
-                    const float4 a = res[2 * sp], c4 = res[2 * sp + 1];
-                    const float u[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
-                    split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
-                }
-                if constexpr (half == 1) bin = bout;
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (own & (1 << t)) *reinterpret_cast<float4*>(xch + ((4 * half + t) * 64 + lane) * 4) = res[t];
+            for (int sp = 0; sp < 2; ++sp) {
+                const float4 a = res[2 * sp], c4 = res[2 * sp + 1];
+                const float u[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+                split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
             }
+            if constexpr (half == 1) bin = bout;
             if constexpr (C == 3) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
         }
     };
@@ -1885,11 +1820,10 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     prof_event(pf, w, lane, 250);
     if (valid) {
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot)
-            if (own & (1 << (ot & 3))) {
-                *reinterpret_cast<float4*>(v.A + l * LDH + 16 * ot + 4 * kg) = Pout[ot];
-                *reinterpret_cast<float4*>(v.B + l * LDH + 16 * ot + 4 * kg) = Qout[ot];
-            }
+        for (int ot = 0; ot < 8; ++ot) {
+            *reinterpret_cast<float4*>(v.A + l * LDH + 16 * ot + 4 * kg) = Pout[ot];
+            *reinterpret_cast<float4*>(v.B + l * LDH + 16 * ot + 4 * kg) = Qout[ot];
+        }
     }
     }
     if (tid == 0) {
@@ -2022,8 +1956,8 @@ __device__ __forceinline__ void equiv_pass3(const Lds& v, Prof& pf) {
     if (more) stream_phase<TEAM, false, false>(v, pf, nullptr);
 }
 
-template <bool TEAM, bool V3>
-__device__ __forceinline__ void head_phase(const Lds& v);
+template <bool TEAM>
+__device__ __forceinline__ void head_phase(const Lds& v, bool v3);
 
 // Dynamics.forward for the own atoms of the molecule resident in LDS: reads v.z (state), the linker mask v.lm, the context
 // words (CX_*: sizes, pointers, model flags, time feature; set by the kernel - CX_PASS / CX_PAR are reset here);
@@ -2041,7 +1975,13 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const int npass = ctx_i(v, CX_NPASS);
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    if (tid == 0) { v.misc[CX_PASS] = (PREC != 0) ? -1 : 0; v.misc[CX_PAR] = 0; }     // (version 3 opens pass CX_PASS + 1: stream_phase)
+    // Per-atom phases: version 3 (stream_phase: atom-stationary GEMM chain, weights streamed through LDS) where a workgroup holds
+    // a whole molecule of MORE THAN 32 atoms - three or four 16-atom tiles, one wave each -, in the f16 modes; version 2 otherwise:
+    // with one or two tiles a step of the stream is a chain of latencies whatever its size, and version 2's seven barriers
+    // per pass beat its twelve (measured round 6, same box: n = 30: version 3 -9 %; teams of 2 / 4: -2 % / 0; n = 35 / 44 / 50
+    // on one compute unit: +4 / +2.5 / +1 %, the ragged C2 chain +4.6 %).  A property of the workgroup, fixed for the launch
+    const bool v3 = (PREC != 0) && !TEAM && nown > 32;
+    if (tid == 0) { v.misc[CX_PASS] = v3 ? -1 : 0; v.misc[CX_PAR] = 0; v.misc[CX_V3] = v3 ? 1 : 0; }     // (version 3 opens pass CX_PASS + 1)
     if (tid < 8) reinterpret_cast<int*>(v.A - L_A + L_PROG)[tid] = 0;      // pair-loop progress slots (pair_phase); barriers follow
     prof_event(pf, w, lane, 1);
     {
@@ -2049,7 +1989,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         __syncthreads();
     }
     const NextPass first = {wp + OFF_BLOCKS, false};
-    if constexpr (PREC == 0) stage_next(v, first, w, tid);          // first pass's W2' image (v.W, v.vec are free here); version 3: its loaders'
+    if (!v3) stage_next(v, first, w, tid);                          // first pass's W2' image (v.W, v.vec are free here); version 3: its loaders'
     // coordinates at entry of the own atoms (x, and x0 for the d0 edge attribute and the velocity); a team gets everybody's
     // from its first exchange
     if (tid < 4 * nown) {
@@ -2096,7 +2036,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
                 else if (k < fin) hin = ctxp[pos * nctx + (k - nf - ct)];
                 acc = fmaf(wrow[k], hin, acc);
             }
-            if constexpr (PREC != 0) {
+            if (v3) {
                 // version 3: st_tile's layout - tile (l / 16, f / 16), lane 16 ((f / 4) & 3) + l % 16, component f & 3
                 hs[HS_HT + ((((l >> 4) * 8 + (f >> 4)) * 64 + 16 * ((f >> 2) & 3) + (l & 15)) * 4) + (f & 3)] = acc;
             } else {
@@ -2111,7 +2051,8 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         block_max(&v.fmax[FM_H0], hmax, lane);
     }
     __syncthreads();
-    if constexpr (PREC != 0) {
+    if (v3) {
+        if constexpr (PREC != 0 && !TEAM) {
         // version 3: the node features live in the HBM scratch (fp32, written above); the projections of the first pass
         if (tid == 0 && beyond_f16_range(__uint_as_float(v.fmax[FM_H0]))) atomicOr(&v.misc[1], NAN_RANGE | 3);
         prof_event(pf, w, lane, 2);
@@ -2125,12 +2066,17 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
         }
         prof_event(pf, w, lane, 3);
         __syncthreads();                                           // the h tiles in the HBM scratch: written by other lanes
-        head_phase<TEAM, true>(v);
+        head_phase<TEAM>(v, true);
+        }
     } else {
     {   // fragment rows of the embedded h -> v.C
-        const float s0 = 1.0f;
+        const float s0 = (PREC != 0) ? scale_for(__uint_as_float(v.fmax[FM_H0])) : 1.0f;
         for (int e = tid; e < nown * 32; e += THREADS)
             put_quad<PREC>(v.C + (e >> 5) * LDH, 4 * (e & 31), *reinterpret_cast<const float4*>(v.B + (e >> 5) * LDH + 4 * (e & 31)), s0);
+        if (PREC != 0 && tid == 0) {
+            v.fmax[FS_HS] = __float_as_uint(s0);
+            if (beyond_f16_range(__uint_as_float(v.fmax[FM_H0]))) atomicOr(&v.misc[1], NAN_RANGE | 3);
+        }
     }
     __syncthreads();
     prof_event(pf, w, lane, 2);
@@ -2149,14 +2095,14 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     prof_event(pf, w, lane, 3);
     __syncthreads();                                               // the h tiles in the HBM scratch: written by other lanes
     // output head: h_final = (Wo h + bo)[:nf], vel = x - x0   (egnn.py:235-237, :420, :430-435)
-    head_phase<TEAM, false>(v);
+    head_phase<TEAM>(v, false);
     }
     prof_event(pf, w, lane, 4);
 }
 
 // (its own context reads: the pass loop above must not keep these alive)
-template <bool TEAM, bool V3>
-__device__ __forceinline__ void head_phase(const Lds& v) {
+template <bool TEAM>
+__device__ __forceinline__ void head_phase(const Lds& v, bool v3) {
     const int tid = lane_ids().tid;
     const int nb = ctx_i(v, 0), nf = ctx_i(v, CX_NF);
     const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
@@ -2171,7 +2117,7 @@ __device__ __forceinline__ void head_phase(const Lds& v) {
         const int r = a & 31;
         const float* wo = wp + OFF_OUT_W + o * HID;
         float acc = wp[OFF_OUT_B + o];
-        if constexpr (V3) {
+        if (v3) {
             // per-atom phases version 3: the node features of atom a in the tiles of wave a / 16 (st_tile), k ascending as well
             const float* hp = hs + HS_HT + ((a >> 4) * 8 * 64 + (a & 15)) * 4;
 #pragma unroll
