@@ -1640,6 +1640,25 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         if (POST && c < 4) return g + G_ST_POST + c * ST_CHUNK;
         return nxb + (NEXT_EQ ? E_ST_PRE : G_ST_PRE) + (c - C_P) * ST_CHUNK;
     };
+    // ---- atom waves: what the epilogues add, requested FIRST: the round trip runs under the scalar chain of the scales below
+    // (vector memory returns in order)
+    // (here, not before the reduction of the slot partials - where the round trip would be free: 64..96 more live registers
+    // across it end up in scratch, +50 % on the whole phase, round 6)
+    float4 t0r[8], hold[8], bb4[8];
+    if (awave) {
+        if constexpr (POST) {
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, ta, ot, lane);
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) {
+                hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
+                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
+            }
+        } else {
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
+        }
+    }
     // ---- scales (a-priori bounds, exactly version 2's)
     const int par = cx.par;
     float hmax = 0.f, aggmax = 0.f, s_agg = 1.f, s_t = 1.f, s_hn = 1.f, inv2 = 1.f;
@@ -1704,24 +1723,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         lds_barrier();                               // the ring is done
         prof_event(pf, w, lane, 250);
     } else {
-    // ---- atom waves: what the epilogues add, requested ahead (vector memory returns in order)
-    // (here, not before the reduction of the slot partials - where the round trip would be free: 64..96 more live registers
-    // across it end up in scratch, +50 % on the whole phase, round 6)
-    float4 t0r[8], hold[8], bb4[8];
-    if (awave) {
-        if constexpr (POST) {
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, ta, ot, lane);
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) {
-                hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
-                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
-            }
-        } else {
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
-        }
-    }
+    // ---- atom waves
     BOp bin, bout;                                   // the GEMM in flight reads `bin` and fills `bout`
     floatx4 acc[4];
     float4 Pout[8], Qout[8];
