@@ -34,6 +34,7 @@ from .noise import PredefinedNoiseSchedule
 
 # measured +2.8 .. 3.2 % on the C2 headline, same box (profiles/r05/ab_split_chain.log); DIFFLINKER_SPLIT_CHAIN=0 turns it off
 SPLIT_CHAIN_DEFAULT = os.environ.get('DIFFLINKER_SPLIT_CHAIN', '1') == '1'
+SPLIT_STAGES_DEFAULT = int(os.environ.get('DIFFLINKER_SPLIT_STAGES', '2'))
 
 
 def compute_units(dev):
@@ -121,6 +122,72 @@ def split_plan(sizes, linkers, n_calls, compute_units, n_layers, sublayers, min_
     return plan
 
 
+def split_plan_stages(sizes, linkers, n_calls, compute_units, n_layers, sublayers, max_stages=6, min_gain=0.02):
+    """The hand-over of split_plan in MORE than two stages (round 6).  split_plan waits until the
+    43..45-atom molecules are done before any compute unit changes hands: the compute units of the 35..40-atom molecules idle for
+    up to a third of the first launch.  Here a stage ends when a number of molecules have completed their chain; the compute
+    units they leave go, at once, to the unfinished molecules with the most work left, which run as TEAMS OF TWO from then on.
+    Every stage is one launch of the molecules still on one compute unit (the current stream) beside one launch of the teams
+    (the side stream); a molecule's state crosses a stage boundary through dl_chain_args.z_state.  Within a stage every workgroup
+    is busy for about the stage's length: molecule b runs floor(length / cost_b) denoiser calls.
+    The number of completions that ends a stage is searched over a small grid; the plan with the smallest predicted makespan and
+    at most `max_stages` stages wins, provided it beats the single launch by `min_gain` (cost model: forward_cost).
+    A function of the sizes alone (cached).  Returns a list of stages ``(q_end [B] - calls completed when the stage ends,
+    teams - molecules it runs on teams of two, singles - on one compute unit)``, or None."""
+    B = len(sizes)
+    if B > compute_units or B == 0:
+        return None
+    key = ('stages', tuple(sizes), tuple(linkers), n_calls, compute_units, n_layers, sublayers, max_stages, min_gain)
+    with _CACHE_LOCK:
+        if key in _PLAN_CACHE:
+            return _PLAN_CACHE[key]
+    table = {}
+    for n, l in set(zip(sizes, linkers)):
+        table[(n, l)] = (forward_cost(n, l, n_layers, sublayers, 1), forward_cost(n, l, n_layers, sublayers, 2))
+    c1 = np.array([table[k][0] for k in zip(sizes, linkers)])
+    c2 = np.array([table[k][1] for k in zip(sizes, linkers)])
+    single = float(c1.max()) * n_calls
+
+    def simulate(events):
+        left = np.full(B, n_calls, dtype=np.int64)
+        mode = np.ones(B, dtype=np.int64)
+        done = np.zeros(B, dtype=np.int64)
+        total, stages = 0.0, []
+        while (left > 0).any():
+            act = np.nonzero(left > 0)[0]
+            free = compute_units - int(mode[act].sum())
+            if stages:                                                  # (the first stage: everybody on one compute unit)
+                cand = [b for b in act if mode[b] == 1]
+                cand.sort(key=lambda b: (-left[b] * c1[b], b))          # most work left first; ties by index: deterministic
+                # teams of two sit in groups of eight molecules (dl_team_max): at most compute_units / 2 of them, rounded down to 8
+                room = (compute_units // 2) // 8 * 8 - int((mode[act] == 2).sum())
+                for b in cand[:max(0, min(free, room))]:
+                    mode[b] = 2
+            cost = np.where(mode == 2, c2, c1)
+            fin = np.sort(left[act] * cost[act])
+            tau = float(fin[min(len(fin) - 1, events - 1)])
+            calls = np.minimum(left[act], np.maximum(1, np.floor(tau / cost[act]).astype(np.int64)))
+            total += float((calls * cost[act]).max())
+            left[act] -= calls
+            done[act] += calls
+            stages.append((done.tolist(), [int(b) for b in act if mode[b] == 2], [int(b) for b in act if mode[b] == 1]))
+            if len(stages) > max_stages:
+                return None
+        return total, stages
+
+    best = None
+    for events in (12, 16, 24, 32, 48, 64, 96, 128):
+        got = simulate(events)
+        if got is not None and len(got[1]) >= 2 and (best is None or got[0] < best[0]):
+            best = got
+    plan = None if best is None or best[0] > (1.0 - min_gain) * single else best[1]
+    with _CACHE_LOCK:
+        if len(_PLAN_CACHE) > 64:
+            _PLAN_CACHE.clear()
+        _PLAN_CACHE[key] = plan
+    return plan
+
+
 # second stream (and its workspace) of the launch that samples the molecules beyond one per compute unit on teams
 # (EDM._sample_chain_fused); per device, shared by every EDM of the process - launches on one stream are ordered
 _SIDE_STREAMS = {}
@@ -175,6 +242,8 @@ class EDM(torch.nn.Module):
         # rounding); the plan is a function of the batch's sizes alone, so a batch is sampled bit for bit the same every time.
         # False: one launch, every molecule on one compute unit for the whole chain.
         self.split_chain = SPLIT_CHAIN_DEFAULT
+        # how many launches deep the hand-over may go (split_plan_stages; 2 = the two launches of round 5: split_plan)
+        self.split_stages = SPLIT_STAGES_DEFAULT
         self.split_singles = os.environ.get('DIFFLINKER_SPLIT_SINGLES', '0') == '1'     # (measured, not adopted: see split_plan)
 
     @staticmethod
@@ -567,13 +636,20 @@ class EDM(torch.nn.Module):
             counts = torch.stack([n_real, lm.ne(0).sum(1)]).cpu()             # ONE device-to-host copy: sizes and linker sizes
             sizes_h, linkers_h = counts[0].tolist(), counts[1].tolist()
             if max(sizes_h) <= int(lib.dl_max_atoms()) and min(sizes_h) > 0:
-                plan = split_plan(sizes_h, linkers_h, T + 1, compute_units(dev), self.dynamics.n_layers,
-                                  int(getattr(self.dynamics, 'inv_sublayers', 2)), allow_singles=bool(self.split_singles))
-                if plan is not None and plan[1] and int(lib.dl_team_max(len(plan[1]))) < 2:
-                    plan = None                                               # the teams of the second phase would not fit at once
+                sub_ = int(getattr(self.dynamics, 'inv_sublayers', 2))
+                if int(self.split_stages) > 2:
+                    plan = split_plan_stages(sizes_h, linkers_h, T + 1, compute_units(dev), self.dynamics.n_layers, sub_,
+                                             max_stages=int(self.split_stages))
+                else:
+                    two = split_plan(sizes_h, linkers_h, T + 1, compute_units(dev), self.dynamics.n_layers, sub_,
+                                     allow_singles=bool(self.split_singles))
+                    # (as a list of stages: everybody on one compute unit up to q_end, then the teams and the single ones to the end)
+                    plan = None if two is None else [(two[0], [], list(range(bs))), ([T + 1] * bs, two[1], two[2])]
+                if plan is not None and any(t_ and int(lib.dl_team_max(len(t_))) < 2 for _, t_, _ in plan):
+                    plan = None                                               # the teams of a stage would not fit at once
         q_end_t = z_state = None
         if plan is not None:
-            q_end_t = torch.tensor(plan[0], dtype=torch.int32, device=dev)
+            q_end_t = torch.tensor(plan[0][0], dtype=torch.int32, device=dev)
             z_state = torch.empty((bs, n, self.n_dims + nf), device=dev)
 
         def chain_args(flags_, steps_, team_, ws_, ws_bytes_, first, count, q_begin=None, q_end=None, skip=None, order_=None):
@@ -623,47 +699,55 @@ class EDM(torch.nn.Module):
                 flags = flags | flags2
                 steps = torch.where(steps2 >= 0, steps2, steps)
             if plan is not None:
-                # second phase: the molecules with the most work left resume from z_state on teams of two (a launch on the side stream),
-                # the others on one compute unit each (a launch on this stream) - side by side, both behind the first launch; a
-                # molecule that ended in the first launch (NaN) is skipped
+                # later stages: the molecules with the most work left resume from z_state on teams of two (a launch on the side stream),
+                # the others on one compute unit each (a launch on this stream) - side by side, both behind the stage before; a
+                # molecule that ended in an earlier launch (NaN) is skipped
                 by_size = lambda idx: torch.tensor(sorted(idx, key=lambda b_: (-sizes_h[b_], b_)), dtype=torch.int32, device=dev)  # noqa: E731
                 after_first = torch.cuda.Event(enable_timing=bool(getattr(self, 'profile_events', False)))
                 after_first.record(cur)
                 self.last_split_event = after_first
-                parts = []
-                if plan[1]:
-                    side = self._side_stream(dev)
-                    rest, m2 = by_size(plan[1]), len(plan[1])
-                    flags2 = torch.zeros(bs, dtype=torch.int32, device=dev)
-                    steps2 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
-                    need2 = int(lib.dl_workspace_bytes(m2, 2))
-                    ws2 = self._side_workspace((dev.index, 'teams'), need2, dev)
-                    args2 = chain_args(flags2, steps2, 2, ws2, need2, 0, m2, q_begin=q_end_t, skip=flags, order_=rest)
-                    side.wait_event(after_first)
-                    _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args2), ctypes.c_void_p(side.cuda_stream)),
-                               'dl_sample_chain_fc (second phase of a split chain: teams of two)')
-                    done2 = torch.cuda.Event()
-                    done2.record(side)
-                    parts.append((flags2, steps2, done2, rest))
-                if plan[2]:
-                    rest1, m1 = by_size(plan[2]), len(plan[2])
-                    flags3 = torch.zeros(bs, dtype=torch.int32, device=dev)
-                    steps3 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
-                    need3 = int(lib.dl_workspace_bytes(m1, 1))
-                    ws3 = self._side_workspace((dev.index, 'singles'), need3, dev)
-                    args3 = chain_args(flags3, steps3, 1, ws3, need3, 0, m1, q_begin=q_end_t, skip=flags, order_=rest1)
-                    _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args3), ctypes.c_void_p(cur.cuda_stream)),
-                               'dl_sample_chain_fc (second phase of a split chain: one compute unit each)')
-                    parts.append((flags3, steps3, None, rest1))
-                for f_, s_, done_, rest_ in parts:
-                    if done_ is not None:
-                        cur.wait_event(done_)
-                        for t_ in (xs, hs, nm, fm, lm, em, ctx, coefs, rest_, chain, noise_x, noise_h, mol_index, q_end_t, z_state, flags):
-                            if t_ is not None:
-                                t_.record_stream(side)
-                    # (the single-compute-unit kernel initialises its molecules' words itself: 0 / -1; merge only what the phase set)
-                    flags = flags | f_
-                    steps = torch.where(s_ >= 0, s_, steps)
+                side = self._side_stream(dev)
+                q_begin_t = q_end_t
+                for si in range(1, len(plan)):
+                    q_end_list, teams_, singles_ = plan[si]
+                    last = si == len(plan) - 1
+                    q_end_s = None if last else torch.tensor(q_end_list, dtype=torch.int32, device=dev)
+                    boundary = torch.cuda.Event()
+                    boundary.record(cur)               # everything of the stages before is behind this point of the current stream
+                    parts = []
+                    if teams_:
+                        rest, m2 = by_size(teams_), len(teams_)
+                        flags2 = torch.zeros(bs, dtype=torch.int32, device=dev)
+                        steps2 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+                        need2 = int(lib.dl_workspace_bytes(m2, 2))
+                        ws2 = self._side_workspace((dev.index, 'teams'), need2, dev)
+                        args2 = chain_args(flags2, steps2, 2, ws2, need2, 0, m2, q_begin=q_begin_t, q_end=q_end_s, skip=flags, order_=rest)
+                        side.wait_event(boundary)
+                        _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args2), ctypes.c_void_p(side.cuda_stream)),
+                                   'dl_sample_chain_fc (a later stage of a split chain: teams of two)')
+                        done2 = torch.cuda.Event()
+                        done2.record(side)
+                        parts.append((flags2, steps2, done2, rest))
+                    if singles_:
+                        rest1, m1 = by_size(singles_), len(singles_)
+                        flags3 = torch.zeros(bs, dtype=torch.int32, device=dev)
+                        steps3 = torch.full((bs,), -1, dtype=torch.int32, device=dev)
+                        need3 = int(lib.dl_workspace_bytes(m1, 1))
+                        ws3 = self._side_workspace((dev.index, 'singles'), need3, dev)
+                        args3 = chain_args(flags3, steps3, 1, ws3, need3, 0, m1, q_begin=q_begin_t, q_end=q_end_s, skip=flags, order_=rest1)
+                        _lib.check(lib.dl_sample_chain_fc(handle, ctypes.byref(args3), ctypes.c_void_p(cur.cuda_stream)),
+                                   'dl_sample_chain_fc (a later stage of a split chain: one compute unit each)')
+                        parts.append((flags3, steps3, None, rest1))
+                    for f_, s_, done_, rest_ in parts:
+                        if done_ is not None:
+                            cur.wait_event(done_)
+                            for t_ in (xs, hs, nm, fm, lm, em, ctx, coefs, rest_, chain, noise_x, noise_h, mol_index, q_begin_t, q_end_s, z_state, flags):
+                                if t_ is not None:
+                                    t_.record_stream(side)
+                        # (the single-compute-unit kernel initialises its molecules' words itself: 0 / -1; merge only what the phase set)
+                        flags = flags | f_
+                        steps = torch.where(s_ >= 0, s_, steps)
+                    q_begin_t = q_end_s
             if getattr(self, 'profile_events', False):
                 ev1.record(cur)
                 self.last_kernel_events = (ev0, ev1)
