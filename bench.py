@@ -505,8 +505,9 @@ def main():
             # second layer, 3 elsewhere - the average over the executed work, synthetic.split_terms)
             terms = synthetic.split_terms(precision, 128, cfg['n_layers'], fin, pairs, pairs_coord, nodes)
             peak, peak_note = F16_MFMA_PEAK_TFLOPS / terms, \
-                f'dense f16 MFMA peak 2500 TFLOP/s / {terms:.2f} split terms per multiply-accumulate; the pair loop is bound by the ' \
-                'issue port its VALU, transcendental and matrix instructions share (profiles/r04), see DESIGN.md'
+                f'dense f16 MFMA peak 2500 TFLOP/s / {terms:.2f} split terms per multiply-accumulate; the pair loop (71 % of a forward) is bound by the ' \
+                'issue port its VALU, transcendental and matrix instructions share (profiles/r04); the per-atom phases (21 %; round 6: an ' \
+                'atom-stationary GEMM chain with LDS-streamed weights, profiles/r06) by chains of latencies, see DESIGN.md'
         else:
             peak, peak_note = FP32_MFMA_PEAK_TFLOPS, 'v_mfma_f32_32x32x2_f32 = fp32 vector peak'
         # fabric-side bytes per launch of the dominant kernel: two rocprofv3 --pmc passes of a T = 50 child, outside the timed
