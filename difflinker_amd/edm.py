@@ -35,6 +35,8 @@ from .noise import PredefinedNoiseSchedule
 # measured +2.8 .. 3.2 % on the C2 headline, same box (profiles/r05/ab_split_chain.log); DIFFLINKER_SPLIT_CHAIN=0 turns it off
 SPLIT_CHAIN_DEFAULT = os.environ.get('DIFFLINKER_SPLIT_CHAIN', '1') == '1'
 SPLIT_STAGES_DEFAULT = int(os.environ.get('DIFFLINKER_SPLIT_STAGES', '2'))
+XCD_ORDER_MODE = int(os.environ.get('DIFFLINKER_XCD_ORDER', '2'))
+XCD_AWARE_ORDER = XCD_ORDER_MODE != 0
 
 
 def compute_units(dev):
@@ -595,6 +597,26 @@ class EDM(torch.nn.Module):
         # with n_b^2, so the big ones are launched first (matters once the batch exceeds the number of compute units)
         n_real = nm.ne(0).sum(1)
         order = torch.argsort(n_real, descending=True, stable=True).to(torch.int32).contiguous()
+        if XCD_AWARE_ORDER and bs <= compute_units(dev) and bs >= 16:
+            # a batch that fits the chip in one wave of workgroups: workgroup k runs on XCD k % 8 (observed dispatch pattern; only
+            # speed depends on it), and the compute units of an XCD share one 4 MB L2 through which each of them streams the same
+            # 5.8 MB of weights per forward.  Molecules of SIMILAR SIZE on one XCD stay in phase, and a weight chunk one of them
+            # pulled in is still there when the others ask: deal the size-sorted molecules to the XCDs in contiguous runs
+            if XCD_ORDER_MODE >= 2:
+                # ... R runs per XCD (2: one from the big end and one from the small end of the sorted batch), dealt in a zig-zag:
+                # the same load on every XCD
+                R = XCD_ORDER_MODE
+                ln = -(-bs // (8 * R))
+                k = torch.arange(8 * R * ln, device=dev)
+                x, j = k % 8, k // 8
+                r = j // ln                                   # which of the XCD's runs
+                run = torch.where(r % 2 == 0, 8 * r + x, 8 * r + 7 - x)
+                idx = run * ln + j % ln
+            else:
+                per = -(-bs // 8)
+                k = torch.arange(8 * per, device=dev)
+                idx = (k % 8) * per + k // 8
+            order = order[idx[idx < bs]].contiguous()
         chain = torch.zeros((keep_frames, bs, n, self.n_dims + nf), device=dev)
         flags = torch.zeros(bs, dtype=torch.int32, device=dev)
         steps = torch.full((bs,), -1, dtype=torch.int32, device=dev)
