@@ -1599,8 +1599,11 @@ struct IC { static constexpr int value = V; };
 // Ends like open_pass: every LDS operand of the next pair loop in place, behind a barrier.
 template <bool TEAM, bool POST, bool NEXT_EQ>
 __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRegs* ar) {
-    constexpr int NC = (POST ? 4 : 0) + (NEXT_EQ ? 4 : 6);
-    constexpr int C_P = POST ? 4 : 0;              // first chunk of the P unit; Q follows, then T0
+    // chunks of the stream.  POST: [W3a' tiles 0-3][W3b' tiles 0-3][W3a' 4-7][W3b' 4-7] (node MLP layer 1: the half that reads h
+    // stays in registers for one chunk - until round 6 it was computed a pass earlier and parked in the HBM scratch as "T0"),
+    // [W4' 0-3][W4' 4-7]; then the next pass's P and Q, two chunks each
+    constexpr int NC = (POST ? 6 : 0) + 4;
+    constexpr int C_P = POST ? 6 : 0;              // first chunk of the P unit; Q follows
     const PassCtx cx = pass_ctx(v);
     const LaneIds q = lane_ids();
     const int tid = q.tid, w = q.w, lane = q.lane;
@@ -1634,27 +1637,15 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     const bool valid = awave && l < nown;
     const int lc = max(min(l, nown - 1), 0);
     auto chunk_src = [&](int c) -> const float* {                        // chunk c of this phase's stream (global)
-        if (POST && c < 4) return g + G_ST_POST + c * ST_CHUNK;
+        if (POST && c < C_P) return g + G_ST_POST + c * ST_CHUNK;
         return nxb + (NEXT_EQ ? E_ST_PRE : G_ST_PRE) + (c - C_P) * ST_CHUNK;
     };
-    // ---- atom waves: what the epilogues add, requested FIRST: the round trip runs under the scalar chain of the scales below
-    // (vector memory returns in order)
-    // (here, not before the reduction of the slot partials - where the round trip would be free: 64..96 more live registers
-    // across it end up in scratch, +50 % on the whole phase, round 6)
-    float4 t0r[8], hold[8], bb4[8];
+    // ---- atom waves: the fp32 node features from the HBM scratch, requested FIRST (the round trip runs under the scalar chain of
+    // the scales below): the B operand of W3a' (POST) or of the projections, and the residual of the node MLP's second layer
+    float4 hold[8];
     if (awave) {
-        if constexpr (POST) {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) t0r[ot] = *st_tile(hs + HS_T0, ta, ot, lane);
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) {
-                hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
-                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
-            }
-        } else {
-#pragma unroll
-            for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
-        }
+        for (int ot = 0; ot < 8; ++ot) hold[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
     }
     // ---- scales (a-priori bounds, exactly version 2's)
     const int par = cx.par;
@@ -1670,8 +1661,9 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         if (tid == 0 && (beyond_f16_range(aggmax) || beyond_f16_range(y3b) || beyond_f16_range(hnb))) atomicOr(&v.misc[1], NAN_RANGE | 3);
         inv2 = inv_pow2(s_t * cload(sc, 4));
     }
-    // scale of the node features as the B operand of the projections: POST - the bound of the new h; else the measured max |h|
-    const float s_hf = POST ? s_hn : scale_for(__uint_as_float(v.fmax[FM_H0 + par]));
+    // scales of the node features as a B operand: of the h this phase starts with (measured max |h|) and, POST, of the new h (its bound)
+    const float s_h0 = scale_for(__uint_as_float(v.fmax[FM_H0 + par]));
+    const float s_hf = POST ? s_hn : s_h0;
     // ---- the aggregate as fp32 rows (POST): into the slot the FOURTH chunk will take, free until chunk 0 has been consumed
     constexpr int AGG_OFF = st_slot_off(st_slot(3, NC));
     if constexpr (POST) {
@@ -1721,8 +1713,12 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         prof_event(pf, w, lane, 250);
     } else {
     // ---- atom waves
-    BOp bin, bout;                                   // the GEMM in flight reads `bin` and fills `bout`
+    // B operands: the node features this phase starts with (W3a' in POST; the projections otherwise), the aggregate, and the
+    // operand being filled by the epilogues (t, then the new h)
+    BOp bh, bagg, bout, bin;
     floatx4 acc[4];
+    float4 t0p[4];                                   // W3a' h + b3 of the four tiles whose W3b' chunk comes next
+    float4 res2[8], bb4[8];                          // residual (the node features once more) and b4: requested one chunk before their use
     float4 Pout[8], Qout[8];
     float hm = 0.f;
     float S1 = 1.f;
@@ -1730,52 +1726,67 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(scn, 6)), scale_for(4.0f * x02) * scale_for(cload(scn, 7)));
     }
-    if constexpr (!POST) {
-        // the B operand of the projections from the fp32 node features
-        if (awave) {
+    if (awave) {
+        // the B operand of W3a' / of the projections from the fp32 node features
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                const float4 a = hold[2 * sl], c4 = hold[2 * sl + 1];
-                const float u[8] = {a.x * s_hf, a.y * s_hf, a.z * s_hf, a.w * s_hf, c4.x * s_hf, c4.y * s_hf, c4.z * s_hf, c4.w * s_hf};
-                split8t(u, bin.hi[sl], bin.lo[sl]);
-            }
+        for (int sl = 0; sl < 4; ++sl) {
+            const float4 a = hold[2 * sl], c4 = hold[2 * sl + 1];
+            const float u[8] = {a.x * s_h0, a.y * s_h0, a.z * s_h0, a.w * s_h0, c4.x * s_h0, c4.y * s_h0, c4.z * s_h0, c4.w * s_h0};
+            split8t(u, bh.hi[sl], bh.lo[sl]);
         }
     }
     prof_event(pf, w, lane, 200);
-    // one step per chunk: barrier -> the output tiles of chunk C (all four, or this wave's share) -> their epilogue
+    // one step per chunk: barrier -> the four output tiles of chunk C -> their epilogue
     auto step = [&](auto C_) {
         constexpr int C = decltype(C_)::value;
         fine_event(pf, w, lane, 230 + C);            // (diagnostics builds) this wave is done with chunk C - 1
         lds_barrier();
         fine_event(pf, w, lane, 210 + C);
         if (!awave) return;
-        constexpr int half = C & 1;                  // tiles 4 half .. 4 half + 3 of the unit = k-slabs 2 half, 2 half + 1 of its result
-        constexpr bool IS_MLP1 = POST && C < 2, IS_MLP2 = POST && C >= 2 && C < 4;
-        constexpr bool IS_P = !(POST && C < 4) && C < C_P + 2, IS_T0 = C >= C_P + 4;
-        // the bias of the chunk's tiles (P: b1' / b5', T0: b3'), requested BEFORE its matrix instructions and before its
+        // what chunk C is: POST 0 / 2: W3a' tiles 0-3 / 4-7, 1 / 3: W3b' of the same tiles, 4 / 5: W4'; then P, P, Q, Q
+        constexpr bool IS_T0 = POST && C < 4 && (C & 1) == 0, IS_MLP1 = POST && C < 4 && (C & 1) == 1, IS_MLP2 = POST && (C == 4 || C == 5);
+        constexpr bool IS_P = C >= C_P && C < C_P + 2;
+        constexpr int half = (POST && C < 4) ? (C >> 1) : (C & 1);       // tiles 4 half .. 4 half + 3 = k-slabs 2 half, 2 half + 1 of the result
+        // the bias of the chunk's tiles (P: b1' / b5', W3a': b3'), requested BEFORE its matrix instructions and before its
         // stores: behind a store the compiler cannot prove disjoint it would wait for the store's completion first
         float4 bias[4];
         if constexpr (IS_P || IS_T0) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-                bias[t] = *reinterpret_cast<const float4*>(vecn + (IS_T0 ? 4 * HID : 0) + 16 * (4 * half + t) + 4 * kg);
+                bias[t] = *reinterpret_cast<const float4*>((IS_T0 ? g + G_VEC + 4 * HID : vecn) + 16 * (4 * half + t) + 4 * kg);
         }
-        if constexpr (POST && C == 0) st_load_rows(bin, lds0 + AGG_OFF, lc, kg, s_agg);
-        st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
+        if constexpr (POST && C == 3) {
+            // (not kept from the phase's first loads: 64 registers across the first layer's four chunks end up in scratch)
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) {
+                res2[ot] = *st_tile(hs + HS_HT, ta, ot, lane);
+                bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
+            }
+        }
+        if constexpr (POST && C == 0) st_load_rows(bagg, lds0 + AGG_OFF, lc, kg, s_agg);
+        if constexpr (IS_T0) st_mma_chunk<st_slot(C, NC)>(lds0, bh, acc, lane);
+        else if constexpr (IS_MLP1) st_mma_chunk<st_slot(C, NC)>(lds0, bagg, acc, lane);
+        else if constexpr (IS_MLP2) st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
+        else st_mma_chunk<st_slot(C, NC)>(lds0, POST ? bin : bh, acc, lane);
         // epilogue of tile t of the chunk: the four values of this lane (features 16 ot + 4 kg + 0..3 of its atom)
         float4 res[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int ot = 4 * half + t, nt = ot >> 1;
-            if constexpr (IS_MLP1) {
-                // node MLP layer 1: t = SiLU(T0 + W3b' agg), times s_t 2^n_tile
+            if constexpr (IS_T0) {
+                // the half of the node MLP's first layer that reads h: W3a' h + b3, waiting for its other half
+                const float inv = inv_pow2(s_h0 * cload(sc, GS_SW_W3A + nt));
+                const float4 b3 = bias[t];
+                t0p[t] = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y), fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
+            } else if constexpr (IS_MLP1) {
+                // node MLP layer 1: t = SiLU(W3a' h + b3 + W3b' agg), times s_t 2^n_tile
                 const float inv = inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)), stn = s_t * cload(sc, GS_NT + nt);
-                const float4 t0 = t0r[ot];
+                const float4 t0 = t0p[t];
                 res[t] = make_float4(silu_u(fmaf(acc[t][0], inv, t0.x)) * stn, silu_u(fmaf(acc[t][1], inv, t0.y)) * stn,
                                      silu_u(fmaf(acc[t][2], inv, t0.z)) * stn, silu_u(fmaf(acc[t][3], inv, t0.w)) * stn);
             } else if constexpr (IS_MLP2) {
                 // node MLP layer 2 + residual: the new h -> HBM scratch (fp32), max |h|, B operand of the projections
-                const float4 hd = hold[ot], b4 = bb4[ot];
+                const float4 hd = res2[ot], b4 = bb4[ot];
                 const float4 hv = make_float4(fmaf(acc[t][0], inv2, hd.x + b4.x), fmaf(acc[t][1], inv2, hd.y + b4.y),
                                               fmaf(acc[t][2], inv2, hd.z + b4.z), fmaf(acc[t][3], inv2, hd.w + b4.w));
                 *st_tile(hs + HS_HT, ta, ot, lane) = hv;
@@ -1786,16 +1797,10 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + nt));
                 const float4 b1 = bias[t];
                 Pout[ot] = make_float4(fmaf(acc[t][0], inv, b1.x), fmaf(acc[t][1], inv, b1.y), fmaf(acc[t][2], inv, b1.z), fmaf(acc[t][3], inv, b1.w));
-            } else if constexpr (!IS_T0) {
+            } else {
                 // Q = W1b' h (W5b' h), times the geometric scale S1 (a team applies its own after the exchange)
                 const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + 4 + nt)) * S1;
                 Qout[ot] = make_float4(acc[t][0] * inv, acc[t][1] * inv, acc[t][2] * inv, acc[t][3] * inv);
-            } else {
-                // T0 = W3a' h + b3 of the GCL being opened -> HBM scratch
-                const float inv = inv_pow2(s_hf * cload(scn, GS_SW_W3A + nt));
-                const float4 b3 = bias[t];
-                *st_tile(hs + HS_T0, ta, ot, lane) = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y),
-                                                                 fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
             }
         }
         if constexpr (IS_MLP1 || IS_MLP2) {
@@ -1807,7 +1812,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 split8t(u, bout.hi[2 * half + sp], bout.lo[2 * half + sp]);
             }
             if constexpr (half == 1) bin = bout;
-            if constexpr (C == 3) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
+            if constexpr (C == 5) block_max(&v.fmax[FM_H0 + (par ^ 1)], hm, lane);
         }
     };
     step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
@@ -2975,11 +2980,19 @@ int32_t dl_model_create(const dl_config* cfg, const float* const* w, int32_t n_t
                 // W4': its rows are the node features themselves (no renumbering there): one scale for the matrix
                 sc[4] = float(pack_unit_f16_uniform(g + G_W4, w4p.data(), HID, 0, 1.0 / c));
                 // the same matrices as the A-operand stream of the atom-stationary per-atom phases (round 6)
-                pack_stream_f16(g + G_ST_POST, w3p.data(), 2 * HID, HID, s3b, true);
-                pack_stream_f16(g + G_ST_POST + UNIT, w4p.data(), HID, 0, 1.0 / c, false);
+                {
+                    // (W3a' and W3b' chunk by chunk: the node MLP's first layer finishes four output tiles before it opens the next)
+                    std::vector<float> ua(UNIT), ub(UNIT);
+                    pack_stream_f16(ua.data(), w3p.data(), 2 * HID, 0, c, true);
+                    pack_stream_f16(ub.data(), w3p.data(), 2 * HID, HID, s3b, true);
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        memcpy(g + G_ST_POST + (2 * h2 + 0) * ST_CHUNK, ua.data() + h2 * ST_CHUNK, ST_CHUNK * sizeof(float));
+                        memcpy(g + G_ST_POST + (2 * h2 + 1) * ST_CHUNK, ub.data() + h2 * ST_CHUNK, ST_CHUNK * sizeof(float));
+                    }
+                }
+                pack_stream_f16(g + G_ST_POST + 2 * UNIT, w4p.data(), HID, 0, 1.0 / c, false);
                 pack_stream_f16(g + G_ST_PRE, w1p.data(), ld1, 0, c, true);
                 pack_stream_f16(g + G_ST_PRE + UNIT, w1p.data(), ld1, HID, c, true);
-                pack_stream_f16(g + G_ST_PRE + 2 * UNIT, w3p.data(), 2 * HID, 0, c, true);
             } else {
                 pack_unit(g + G_W1A, w1p.data(), ld1, 0, c); pack_unit(g + G_W1B, w1p.data(), ld1, HID, c);
                 pack_unit(g + G_W3A, w3p.data(), 2 * HID, 0, c); pack_unit(g + G_W3B, w3p.data(), 2 * HID, HID, s3b);

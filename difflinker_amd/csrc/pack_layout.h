@@ -55,11 +55,12 @@ constexpr int SIN_K = 24;                            // 6 frequencies x (sin, co
 // phases of egnn_fc.hip (stream_phase): 16-feature output tiles x 32-wide k-slabs of v_mfma_f32_16x16x32_f16, in the order they
 // are consumed - a unit = two 32 KB chunks of four output tiles, chunk[ot][slab][hi | lo][lane][8 fp16], lane (r, kg) holding
 // part(sw * W'[16 ot + r][kslot(slab, kg, e)]) with the k-slots in the order the previous GEMM's accumulators leave them
-// (stream_kslot).  G_ST_POST: W3b', W4' (after this GCL's pair loop); G_ST_PRE: W1a', W1b', W3a' (what opens this GCL).
+// (stream_kslot).  G_ST_POST, after this GCL's pair loop: W3a' and W3b' interleaved chunk by chunk (tiles 0-3 of one, of the
+// other, tiles 4-7 of one, of the other), then W4'; G_ST_PRE, what opens this GCL: W1a', W1b'.
 // Same weights, scales and renumbering as the units above (one sc[] block serves both); the exact-fp32 mode leaves them zero.
 constexpr int G_ST_POST = 7 * UNIT + 7 * HID + G_SCALE_SIZE + SIN_K * HID;
-constexpr int G_ST_PRE = G_ST_POST + 2 * UNIT;
-constexpr int GCL_SIZE = G_ST_PRE + 3 * UNIT;
+constexpr int G_ST_PRE = G_ST_POST + 3 * UNIT;
+constexpr int GCL_SIZE = G_ST_PRE + 2 * UNIT;
 // equivariant update: units W5a', W5b', W6' (both LDS images), vectors
 constexpr int E_W5A = 0, E_W5B = UNIT, E_W6 = 2 * UNIT, E_W6T = 3 * UNIT;
 constexpr int E_VEC = 4 * UNIT;                       // b5', wr', wd', b6', w7'       (5 x 128)
