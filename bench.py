@@ -222,8 +222,8 @@ def measure_traffic(a, cfg, child_T=50):
     total = (fetch + write) * (cfg['T'] + 1)
     return total, (f'measured by this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) over a child process sampling the same '
                    f'batch with T = {child_T}; per forward {fetch / 1e6:.0f} MB fetched (FETCH_SIZE x2, gfx950) + {write / 1e6:.0f} MB '
-                   f'written, x{cfg["T"] + 1} forwards; fabric-side, Infinity-Cache hits included (the T0 / residual tiles a '
-                   f'workgroup parks in its HBM scratch and the weights every XCD streams); the algorithmic bytes are ~2 MB per forward')
+                   f'written, x{cfg["T"] + 1} forwards; fabric-side, Infinity-Cache hits included (the fp32 node-feature tiles a '
+                   f'workgroup parks in its HBM scratch and the L2 misses of the weight stream); the algorithmic bytes are ~2 MB per forward')
 
 
 def time_chains(edm, inp, steps=1, warmup=1):
