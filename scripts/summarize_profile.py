@@ -50,7 +50,7 @@ if 'WRITE_SIZE' in out:
     d['hbm_write_bytes_per_launch'] = out['WRITE_SIZE'] * 1024
 d['note'] = ('per launch of ' + kernel + ' (' + tag + ': ' + str(forwards) + ' forwards, C2 ragged batch, f16x3); FETCH_SIZE/WRITE_SIZE are in KiB, '
              'FETCH doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); fabric-side counters, '
-             'Infinity-Cache hits included: the T0 / residual tiles a workgroup parks in its HBM scratch and the weights every XCD streams; the algorithmic '
+             'Infinity-Cache hits included: the fp32 node-feature tiles a workgroup parks in its HBM scratch and the L2 misses of the weight stream; the algorithmic '
              'bytes are ~2 MB per forward')
 out['_derived'] = d
 json.dump(out, open(os.path.join(dst, f'pmc_chain_kernel_{tag}.json'), 'w'), indent=1)
