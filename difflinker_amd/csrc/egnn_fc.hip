@@ -93,10 +93,12 @@ struct Lds {
     int *idx, *rcv, *rpos, *misc;
     unsigned* fmax;
     float* dummy;
+    int w;                 // this wave's index in the workgroup (an SGPR: see lane_ids)
 };
 
 __device__ __forceinline__ Lds lds_view(float* base) {
     Lds v;
+    v.w = __builtin_amdgcn_readfirstlane(int(threadIdx.x) >> 6);
     v.A = base + L_A; v.B = base + L_B; v.C = base + L_C; v.W = base + L_W; v.vec = base + L_VEC;
     v.xs = base + L_XS; v.x0 = base + L_X0; v.z = base + L_Z;
     v.aggx = base + L_B;                       // coordinate aggregate of the own atoms [n_own][4]: over Q, dead once a pair loop is over
@@ -218,20 +220,25 @@ __device__ __forceinline__ void stage_dma(const Lds& v, const float* __restrict_
                                          16, 0, 0);
 }
 
-// Per-lane indices re-derived from an OPAQUE copy of the thread index.  Everything that is computed from the lane index
-// before a pair loop and used again after it would have to live across the loop - i.e. be spilled (the loop takes every
-// VGPR) and reloaded one by one, each reload paying an L2 round trip behind whatever vector-memory traffic is queued.
-// Re-deriving costs a handful of VALU instructions per phase and leaves nothing per-lane alive across the loop.
+// Per-lane indices re-derived where they are used.  Everything that is computed from the lane index before a pair loop and used
+// again after it would have to live across the loop - i.e. be spilled (the loop takes every VGPR) and reloaded one by one, each
+// reload paying an L2 round trip behind whatever vector-memory traffic is queued.  Until round 6 they were re-derived from an opaque
+// copy of threadIdx.x - but that register (v0 at kernel entry) then lives across the whole kernel itself: it was spilled at
+// entry and reloaded from scratch at ~40 places, an s_waitcnt vmcnt(0) each.  Now: the lane from v_mbcnt (of an opaque zero, so
+// that no two derivations are merged into one long-lived value), the wave index from an SGPR set at kernel entry (Lds::w).
 struct LaneIds {
     int tid, w, lane, c, hh, nt, mt;
 };
-__device__ __forceinline__ LaneIds lane_ids() {
-    int t = threadIdx.x;
-    asm volatile("" : "+v"(t));
+__device__ __forceinline__ LaneIds lane_ids(const Lds& v) {
+    int z = 0;
+    asm volatile("" : "+v"(z));
     LaneIds q;
-    q.tid = t;
-    q.w = __builtin_amdgcn_readfirstlane(t >> 6);
-    q.lane = t & 63;
+    q.lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+    q.w = v.w;
+    asm volatile("" : "+s"(q.w));              // (opaque too: what is derived from it stays local to the place that derives it)
+    q.tid = 64 * q.w + q.lane;
+    asm volatile("" : "+v"(q.tid));            // (opaque: with the sum visible the compiler splits every index derived from it into a
+                                               // scalar and a vector part and doubles the kernel's SGPR spills)
     q.c = q.lane & 31; q.hh = q.lane >> 5;
     q.nt = q.w & 3; q.mt = q.w >> 2;
     return q;
@@ -1174,7 +1181,7 @@ template <int PREC, bool TEAM>
 __device__ __forceinline__ void open_pass(const Lds& v, int nb, int nown, const NextPass nx, float* __restrict__ hs, Prof& pf,
                                           const PreW2& pw, int next_pass, int par) {
     if (nx.base == nullptr) return;
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int w = q.w, lane = q.lane;
     const float s_hf = (PREC != 0) ? __uint_as_float(v.fmax[FS_HS]) : 1.0f;
     const float* sc = nx.base + (nx.equiv ? E_SCALE : G_SCALE);
@@ -1199,7 +1206,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     const int nb = cx.nb, N = cx.N, par = cx.par;
     const int8_t* emask = cx.em;
     const float* sc = cx.g + G_SCALE;
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int tid = q.tid, w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 12);
     if (tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }      // (max |h| is kept in every arithmetic mode: equiv_pass2's finiteness proof)
@@ -1231,7 +1238,7 @@ __device__ __forceinline__ void gcl_pass2(const Lds& v, Prof& pf) {
     const float* vecs = g + G_VEC;
     const float* sc = g + G_SCALE;
     const bool mean = (cx.flags & 4) != 0;
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int tid = q.tid, w = q.w, lane = q.lane, c = q.c, hh = q.hh, nt = q.nt, mt = q.mt;
     const bool active = (mt == 0) || (nown > 32);
     // layer 1's fragments and T0, AHEAD of the next W2' image in the memory pipeline
@@ -1378,7 +1385,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     const int8_t* emask = cx.em;
     const float* sc = cx.g + E_SCALE;
     const float norm_constant = ctx_f(v, CX_NORMC);
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 32);
     float sa = 1.0f, accs = 1.0f;
@@ -1426,7 +1433,7 @@ __device__ __forceinline__ void equiv_pass2(const Lds& v, Prof& pf) {
     const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
     float* hs = cx.hs;
     const NextPass nx = cx.nx;
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int tid = q.tid, w = q.w, lane = q.lane;
     PreW2 pw;
     load_pre2(pw, nx, w, lane, nown);            // the fragments the next block opens with, under the reduction
@@ -1605,7 +1612,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
     constexpr int NC = (POST ? 6 : 0) + 4;
     constexpr int C_P = POST ? 6 : 0;              // first chunk of the P unit; Q follows
     const PassCtx cx = pass_ctx(v);
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int tid = q.tid, w = q.w, lane = q.lane;
     const int nb = cx.nb;
     const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
@@ -1853,7 +1860,7 @@ __device__ __forceinline__ void gcl_pass3(const Lds& v, Prof& pf) {
     const int nb = cx.nb, N = cx.N, par = cx.par;
     const int8_t* emask = cx.em;
     const float* sc = cx.g + G_SCALE;
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int tid = q.tid, w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 12);
     if (tid == 0) { v.fmax[FM_H0 + (par ^ 1)] = 0u; v.fmax[FM_AGG] = 0u; }
@@ -1874,7 +1881,7 @@ __device__ __forceinline__ void gcl_pass3(const Lds& v, Prof& pf) {
     {
         const PassCtx cx = pass_ctx(v);
         const int nown = TEAM ? ctx_i(v, TM_NOWN) : cx.nb;
-        const LaneIds q = lane_ids();
+        const LaneIds q = lane_ids(v);
         next_eq = cx.nx.equiv;
         lds_barrier();                         // partial rows complete
         prof_event(pf, q.w, q.lane, 20);
@@ -1897,7 +1904,7 @@ __device__ __forceinline__ void equiv_pass3(const Lds& v, Prof& pf) {
     const int8_t* emask = cx.em;
     const float* sc = cx.g + E_SCALE;
     const float norm_constant = ctx_f(v, CX_NORMC);
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int w = q.w, lane = q.lane;
     prof_event(pf, w, lane, 32);
     const float hmax = __uint_as_float(v.fmax[TEAM ? FM_HG : FM_H0 + par]);
@@ -1930,7 +1937,7 @@ __device__ __forceinline__ void equiv_pass3(const Lds& v, Prof& pf) {
     const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
     const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
     const bool more = cx.nx.base != nullptr;
-    const LaneIds q = lane_ids();
+    const LaneIds q = lane_ids(v);
     const int tid = q.tid, lane = q.lane;
     lds_barrier();                         // partial triples complete
     const float xscale = (cx.flags & 4) ? 1.0f / float(N) : ((cx.flags & 2) ? ctx_f(v, CX_INVNORM) : 1.0f);
@@ -1968,7 +1975,7 @@ __device__ __forceinline__ void head_phase(const Lds& v, bool v3);
 // writes eps_hat[l][0:3+nf] of own atom l into v.A (row stride DMAX) and ORs NaN bits into v.misc[1].
 template <int PREC, bool TEAM, bool ATT>
 __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
-    const int tid = lane_ids().tid;
+    const int tid = lane_ids(v).tid;
     const int nb = ctx_i(v, 0);
     const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
     const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
@@ -2107,7 +2114,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
 // (its own context reads: the pass loop above must not keep these alive)
 template <bool TEAM>
 __device__ __forceinline__ void head_phase(const Lds& v, bool v3) {
-    const int tid = lane_ids().tid;
+    const int tid = lane_ids(v).tid;
     const int nb = ctx_i(v, 0), nf = ctx_i(v, CX_NF);
     const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
     const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
@@ -2304,7 +2311,7 @@ __global__ void __launch_bounds__(THREADS) egnn_forward_fc_kernel(FwdArgs p) {
     forward_molecule2<PREC, TEAM, ATT>(v, pf);
     {   // results of the own atoms (arguments and sizes re-read: see the pass context)
         const auto* P = kargs<FwdArgs>();
-        const int tid = lane_ids().tid;
+        const int tid = lane_ids(v).tid;
         const int mol = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), N = P->N, D = 3 + P->md.nf;
         const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
         const int S2 = TEAM ? ctx_i(v, TM_S) : 1, rank2 = TEAM ? ctx_i(v, TM_RANK) : 0;
@@ -2337,7 +2344,7 @@ template <int PREC, bool TEAM, bool ATT>
 __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     {
         const auto* P = kargs<ChainArgs>();
-        const int tid = lane_ids().tid;
+        const int tid = lane_ids(v).tid;
         if (tid == 0) {
             const float t = (q == P->a.T) ? 0.0f : P->a.coefs[q].t;                  // last forward: p(x,h | z_0), edm.py:210-242
             v.misc[CX_TFEAT] = __float_as_int(t);
@@ -2349,7 +2356,7 @@ __device__ __forceinline__ bool chain_step2(const Lds& v, int q) {
     pf.n = 0;
     forward_molecule2<PREC, TEAM, ATT>(v, pf);
     const auto* P = kargs<ChainArgs>();
-    const int tid = lane_ids().tid;
+    const int tid = lane_ids(v).tid;
     const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0);
     const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
     const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
@@ -2493,7 +2500,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
         if (!chain_step2<PREC, TEAM, ATT>(v, q)) return;
     if (qe <= T) {                                                 // stopped early: hand the state over (dl_chain_args.z_state)
         const auto* P = kargs<ChainArgs>();
-        const int tid = lane_ids().tid;
+        const int tid = lane_ids(v).tid;
         const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), D = 3 + P->md.nf, N = P->a.N;
         const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
         const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;
@@ -2505,7 +2512,7 @@ __global__ void __launch_bounds__(THREADS) sample_chain_fc_kernel(ChainArgs p) {
     }
     {   // frame 0: the final sample [x, one_hot(h)] of the own atoms
         const auto* P = kargs<ChainArgs>();
-        const int tid = lane_ids().tid;
+        const int tid = lane_ids(v).tid;
         const int b = ctx_i(v, CX_MOL), nb = ctx_i(v, 0), nf = P->md.nf, D = 3 + nf;
         const int nown = TEAM ? ctx_i(v, TM_NOWN) : nb;
         const int S = TEAM ? ctx_i(v, TM_S) : 1, rank = TEAM ? ctx_i(v, TM_RANK) : 0;

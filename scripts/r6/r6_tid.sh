@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B: lane indices from v_mbcnt + an SGPR wave index (no scratch reloads of threadIdx.x) against the library of the commit before
+O=gpurun_out/r6/tid
+V=difflinker_amd/variants/lib_prev.so
+mkdir -p $O
+timeout 1500 python -m pytest tests/test_gpu_round6.py tests/test_gpu_parity.py tests/test_gpu_team.py tests/test_gpu_cabi.py -q -x > $O/pytest.log 2>&1; grep -a "passed\|failed\|error" $O/pytest.log | tail -n 3
+run() {
+  python bench.py --steps 3 --warmup 1 --no-secondary --no-cpu-baseline --no-traffic 2>/dev/null | tail -1 | \
+    python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', 'mol/s %.1f' % d['value'], 'kernel_ms %.1f' % d['roofline']['kernel_ms'], d.get('split_chain'))"
+}
+for lib in "" $V "" $V "" $V; do DIFFLINKER_HIP_LIB=$lib run "lib ${lib:-product}"; done | tee $O/ab.log
+for cfg in "--batch 256 --team 1 --n 35" "--batch 256 --team 1 --n 44" "--batch 256 --team 1 --n 50" "--batch 64 --team 4" "--batch 128 --team 2" "--batch 256 --team 1 --n 30"; do
+  for lib in "" $V; do
+    DIFFLINKER_HIP_LIB=$lib timeout 300 python scripts/time_forward.py --raw --iters 50 $cfg 2>&1 | tail -1
+  done
+done | tee $O/forward.log
