@@ -5,22 +5,24 @@
 // EGNN.forward :218-238, EquivariantBlock :157-178, GCL :45-80, EquivariantUpdate :101-125,
 // coord2diff :295-301, unsorted_segment_sum :304-320, EDM.sample_chain src/edm.py:126-242.
 //
-// Design:
-//   * one 512-thread workgroup (8 wave64) per molecule; the molecule's whole EGNN state lives in
-//     LDS for the entire forward (or the entire T-step chain): per-atom first-layer projections
-//     P,Q [n,128], the message aggregate / node features [n,128], coordinates, masks.
-//   * the O(n^2) edge pass never materialises an edge tensor: each wave takes tiles of 32 (i,j)
-//     pairs, generates the first-layer activations SiLU(P_i + Q_j + r*w_r + d0*w_d) straight into
-//     MFMA A-fragments, multiplies by the 128x128 second-layer weights (LDS-resident, 64 KB) with
-//     v_mfma_f32_32x32x2_f32 (exact fp32), applies SiLU + edge mask in the accumulator layout and
-//     reduces over j with LDS float atomics (GCL) or a 32-lane butterfly (coordinate head).
-//   * per-node GEMMs (first-layer projections, node MLP) run on the same MFMA with the atom index
-//     as the M dimension; their weights stream from L2 in a pre-packed fragment order.
-//   * SiLU is evaluated as y * rcp(1 + exp2(y)) with y = -log2(e) * pre-activation; the constant is
-//     folded into the packed weights on the host (dl_model_create), so the device does one v_exp_f32
-//     and one v_rcp_f32 per activation.
-//   * no HBM traffic inside a forward besides the (L2-resident) weights: inputs are read once,
-//     eps_hat written once.
+// Design (sections 4 and 5):
+//   * one 512-thread workgroup (8 wave64) per molecule - or a TEAM of 2 / 4 / 8 workgroups; the molecule's state lives in LDS for
+//     the whole forward and the whole T-step chain (sample_chain_fc_kernel: one launch per chain, the sampler algebra and the
+//     Philox draws between the forwards in the kernel): first-layer projections P, Q [n,128], coordinates, masks, the chain
+//     state z; every LDS address is a compile-time constant (L_* below).
+//   * the O(n^2) edge pass never materialises an edge tensor (pair_phase): receiver-stationary, both edge layers TRANSPOSED
+//     (features x pairs) so that the accumulator layout of the first layer is the B-operand layout of the second; messages are
+//     summed in the receiver's accumulators, the 256 slot partials added in a fixed order afterwards (deterministic, no atomics).
+//   * arithmetic (template PREC): 0 = exact fp32 (v_mfma_f32_32x32x2_f32), 1 = f16x3 - every operand scaled by a power of two,
+//     split into fp16 hi + lo, three v_mfma_f32_32x32x16_f16 terms, fp32 accumulation: fp32-class results (the default) -,
+//     2 = two terms in the GCL edge models (opt-in).  Scales come from a-priori bounds (host: row-L1 norms; device: max |h|, |x|^2).
+//   * per-atom GEMMs (node MLP, the next pass's projections): version 2 - atoms as MFMA rows on all eight waves, fragments from
+//     L2 -, and, for a molecule of 33..55 atoms on one workgroup in the f16 modes, version 3 (stream_phase): atom-stationary,
+//     a register-to-register chain on v_mfma_f32_16x16x32_f16 with the weights streamed through an LDS ring by four loader waves.
+//   * SiLU is y * rcp(1 + exp2(y)) with y = -log2(e) * pre-activation, the constant folded into the packed weights on the host
+//     (dl_model_create): one v_exp_f32 and one v_rcp_f32 per activation.
+//   * HBM traffic inside a forward: the (L2-resident) weights and a per-workgroup scratch for the fp32 node features; inputs are
+//     read once per chain, the kept frames written once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
