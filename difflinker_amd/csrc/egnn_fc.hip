@@ -69,6 +69,12 @@ constexpr int L_FMAX = L_MISC + MISC_WORDS;           // f16x3 magnitude bounds 
 constexpr int L_DUMMY = L_FMAX + 8;                   // sink row for the stores of tile rows >= n_own (branch-free)
 constexpr int L_PROG = L_DUMMY + LDH;                 // pair-loop progress of the 8 waves (fair sharing of a SIMD between its two waves)
 constexpr int L_TOTAL = L_PROG + 8;
+// A row of 128 zeros for the kernels with ONE workgroup per molecule: the coordinate rows 56..87 of v.xs, which only a team uses (LDS
+// has not a byte to spare).  Slots and steps of a pair loop that hold no pair (the last wave's spare slots, a last chunk one sender
+// short: 10 % of the slot-steps of the C2 batch) read their P and Q rows there and take r = d0 = 0: the first layer comes out as
+// SiLU(0) = 0, the second layer multiplies ZERO columns - under the power cap the energy an idle column does not burn is clock.
+constexpr int L_ZROW = L_XS + 4 * 56;
+static_assert(L_ZROW + HID <= L_X0 && 56 >= NMAX + 1 && (L_ZROW % 4) == 0, "the zero row sits in the team-only part of the coordinate rows");
 constexpr size_t LDS_BYTES = size_t(L_TOTAL) * 4;
 static_assert(LDS_BYTES <= 163840, "LDS layout exceeds 160 KiB");
 static_assert((L_B % 4) == 0 && (L_C % 4) == 0 && (L_W % 4) == 0 && (L_VEC % 4) == 0 && (L_XS % 4) == 0 &&
@@ -412,7 +418,10 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             // ~100 LDS reads out of the loop into registers it does not have (= scratch) and reloads them every iteration
             int opq = 0;
             asm volatile("" : "+s"(opq));
-            const float* Pp = Pp_ + opq;
+            // (one workgroup per molecule, f16 modes) a slot-step without a pair reads the zero row: see L_ZROW
+            constexpr bool ZIDLE = !TEAM && PREC != 0;
+            const float* zrow = v.A - L_A + L_ZROW + 4 * hh;
+            const float* Pp = ((ZIDLE && t >= jn) ? zrow : Pp_) + opq;
             const float* bias_p = bias_p_ + opq;
             const float* w7_p = w7_p_ + opq;
             loop_event(pf, w, lane, 50);
@@ -433,7 +442,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
             const float ex = yi.x - yj.x, ey = yi.y - yj.y, ez = yi.z - yj.z;
             const float r = dx * dx + dy * dy + dz * dz;             // squared distance, current x  (egnn.py:298)
             const float d0 = ex * ex + ey * ey + ez * ez;            // squared distance at forward entry (:220)
-            const float* Qp = v.B + j * LDH + 4 * hh;
+            const float* Qp = (ZIDLE && !ok) ? zrow : v.B + j * LDH + 4 * hh;
             float ssum = 0.0f;
 
             // bias (and w7') vectors of a 32-feature tile: four broadcast float4 per lane
@@ -551,7 +560,7 @@ __device__ __forceinline__ void pair_phase(const Lds& v, int nb, int w, int lane
                 // Only slab 0 is produced without MFMAs beside it and only slab 7's MFMAs have no VALU beside them.
                 // Fragments are double-buffered (2 x 8 registers), W2' fragments and P/Q rows arrive one group ahead.
                 constexpr bool TWO = (PREC == 2) && !EQUIV && !ATT;
-                const float xv = (hh ? d0 : r) * sX;
+                const float xv = (ZIDLE && !ok) ? 0.0f : (hh ? d0 : r) * sX;
                 const float xh_ = __uint_as_float(__float_as_uint(xv) & 0xffffe000u);
                 const uint4 xf = make_uint4(__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xh_, xh_)),
                                             __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(xv - xh_, 0.0f)), 0u, 0u);
@@ -1996,6 +2005,7 @@ __device__ __forceinline__ void forward_molecule2(const Lds& v, Prof& pf) {
     const bool v3 = (PREC != 0) && !TEAM && nown > 32;
     if (tid == 0) { v.misc[CX_PASS] = v3 ? -1 : 0; v.misc[CX_PAR] = 0; v.misc[CX_V3] = v3 ? 1 : 0; }     // (version 3 opens pass CX_PASS + 1)
     if (tid < 8) reinterpret_cast<int*>(v.A - L_A + L_PROG)[tid] = 0;      // pair-loop progress slots (pair_phase); barriers follow
+    if (!TEAM && tid < HID) (v.A - L_A + L_ZROW)[tid] = 0.0f;               // the zero row of the idle slot-steps (pair_phase); barriers follow
     prof_event(pf, w, lane, 1);
     {
         if (tid < 8) v.fmax[tid] = 0u;
