@@ -1744,12 +1744,16 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
         const float x2 = __uint_as_float(v.fmax[FM_X2]), x02 = __uint_as_float(v.fmax[FM_X02]);
         S1 = fminf(scale_for(4.0f * x2) * scale_for(cload(scn, 6)), scale_for(4.0f * x02) * scale_for(cload(scn, 7)));
     }
+    // (the columns of a tile's padding atoms - 14 of 64 at n = 50 - enter every GEMM as ZEROS: their operand scales are 0.  Nothing
+    // of them is ever read, and a zero column costs the matrix pipe less energy, which under the power cap is clock)
+    const float live = valid ? 1.0f : 0.0f;
     if (awave) {
         // the B operand of W3a' / of the projections from the fp32 node features
+        const float sb = s_h0 * live;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {
             const float4 a = hold[2 * sl], c4 = hold[2 * sl + 1];
-            const float u[8] = {a.x * s_h0, a.y * s_h0, a.z * s_h0, a.w * s_h0, c4.x * s_h0, c4.y * s_h0, c4.z * s_h0, c4.w * s_h0};
+            const float u[8] = {a.x * sb, a.y * sb, a.z * sb, a.w * sb, c4.x * sb, c4.y * sb, c4.z * sb, c4.w * sb};
             split8t(u, bh.hi[sl], bh.lo[sl]);
         }
     }
@@ -1781,7 +1785,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 bb4[ot] = *reinterpret_cast<const float4*>(g + G_VEC + 5 * HID + 16 * ot + 4 * kg);
             }
         }
-        if constexpr (POST && C == 0) st_load_rows(bagg, lds0 + AGG_OFF, lc, kg, s_agg);
+        if constexpr (POST && C == 0) st_load_rows(bagg, lds0 + AGG_OFF, lc, kg, s_agg * live);
         if constexpr (IS_T0) st_mma_chunk<st_slot(C, NC)>(lds0, bh, acc, lane);
         else if constexpr (IS_MLP1) st_mma_chunk<st_slot(C, NC)>(lds0, bagg, acc, lane);
         else if constexpr (IS_MLP2) st_mma_chunk<st_slot(C, NC)>(lds0, bin, acc, lane);
@@ -1798,7 +1802,7 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                 t0p[t] = make_float4(fmaf(acc[t][0], inv, b3.x), fmaf(acc[t][1], inv, b3.y), fmaf(acc[t][2], inv, b3.z), fmaf(acc[t][3], inv, b3.w));
             } else if constexpr (IS_MLP1) {
                 // node MLP layer 1: t = SiLU(W3a' h + b3 + W3b' agg), times s_t 2^n_tile
-                const float inv = inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)), stn = s_t * cload(sc, GS_NT + nt);
+                const float inv = inv_pow2(s_agg * cload(sc, GS_SW_W3B + nt)), stn = s_t * cload(sc, GS_NT + nt) * live;
                 const float4 t0 = t0p[t];
                 res[t] = make_float4(silu_u(fmaf(acc[t][0], inv, t0.x)) * stn, silu_u(fmaf(acc[t][1], inv, t0.y)) * stn,
                                      silu_u(fmaf(acc[t][2], inv, t0.z)) * stn, silu_u(fmaf(acc[t][3], inv, t0.w)) * stn);
@@ -1809,7 +1813,8 @@ __device__ __forceinline__ void stream_phase(const Lds& v, Prof& pf, const AggRe
                                               fmaf(acc[t][2], inv2, hd.z + b4.z), fmaf(acc[t][3], inv2, hd.w + b4.w));
                 *st_tile(hs + HS_HT, ta, ot, lane) = hv;
                 if (valid) hm = fmaxf(fmaxf(hm, fmaxf(fabsf(hv.x), fabsf(hv.y))), fmaxf(fabsf(hv.z), fabsf(hv.w)));
-                res[t] = make_float4(hv.x * s_hn, hv.y * s_hn, hv.z * s_hn, hv.w * s_hn);
+                const float shl = s_hn * live;
+                res[t] = make_float4(hv.x * shl, hv.y * shl, hv.z * shl, hv.w * shl);
             } else if constexpr (IS_P) {
                 // P = W1a' h + b1 (W5a' h + b5): kept in registers until the ring has let go of the P region
                 const float inv = inv_pow2(s_hf * cload(scn, (NEXT_EQ ? ES_SW_W5A : GS_SW_W1A) + nt));
