@@ -310,6 +310,12 @@ __device__ __forceinline__ SlotPlan slot_plan(int nrec, int nb) {
     SlotPlan sp;
     sp.g = min(NSLOT / max(nrec, 1), nb);
     sp.q = (nb + sp.g - 1) / sp.g;
+    // ... and of the plans with that many steps the one with the FEWEST slots: a wave without slots skips the loop (8 linker atoms
+    // as receivers of 50 senders: 25 instead of 32 slots each, 7 waves instead of 8; 36 atoms: 6 instead of 7, 7 waves) - a step
+    // costs its energy per ACTIVE wave, and under the power cap energy is time (round 6)
+    sp.g = (nb + sp.q - 1) / max(sp.q, 1);
+    // (one or two MORE steps where that takes fewer wave-steps still - 38 atoms: 6 waves x 8 instead of 8 x 7 - measured slower, +5 %:
+    // the number of steps is the critical path; profiles/r06/ab_fewest_slots_plan.log)
     return sp;
 }
 

@@ -9,7 +9,7 @@ run() {
     python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', 'mol/s %.1f' % d['value'], 'kernel_ms %.1f' % d['roofline']['kernel_ms'], d.get('split_chain'))"
 }
 for lib in "" $V "" $V "" $V; do DIFFLINKER_HIP_LIB=$lib run "lib ${lib:-product}"; done | tee $O/ab.log
-for cfg in "--batch 256 --team 1 --n 35" "--batch 256 --team 1 --n 38" "--batch 256 --team 1 --n 42" "--batch 256 --team 1 --n 46" "--batch 256 --team 1 --n 50" "--batch 64 --team 4" "--batch 128 --team 2" "--batch 256 --team 1 --n 30"; do
+for cfg in "--batch 256 --team 1 --n 35" "--batch 256 --team 1 --n 36" "--batch 256 --team 1 --n 44" "--batch 256 --team 1 --n 46" "--batch 256 --team 1 --n 50" "--batch 64 --team 4" "--batch 128 --team 2" "--batch 256 --team 1 --n 30"; do
   for lib in "" $V; do
     DIFFLINKER_HIP_LIB=$lib timeout 300 python scripts/time_forward.py --raw --iters 50 $cfg 2>&1 | tail -1
   done
